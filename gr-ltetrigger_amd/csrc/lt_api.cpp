@@ -1,0 +1,734 @@
+// C-ABI of the gfx950 LTE cell-search path (include/ltetrigger_hip.h).
+// Host code only: handle management, staging copies, stream/event plumbing, error mapping.
+// There is deliberately no CPU implementation of any compute entry point here.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/ltetrigger_hip.h"
+#include "lt_launch.h"
+#include "lt_tables.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(LT_ERROR, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                  __LINE__);                                                                     \
+  } while (0)
+
+// Constant tables, uploaded once per device and shared by every handle on it.
+struct DeviceCtx {
+  lt::DeviceTables *d_tab = nullptr;
+};
+std::mutex g_ctx_mu;
+std::map<int, DeviceCtx> g_ctx;
+
+int use_device(int device)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(LT_ERROR, "no HIP device available (%s); this library has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= n) return fail(LT_ERROR_INVALID_INPUTS, "device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  return LT_OK;
+}
+
+int get_tables(int device, const lt::DeviceTables **out)
+{
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  DeviceCtx &c = g_ctx[device];
+  if (!c.d_tab) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(LT_ERROR, "device %d is %s; this library only carries gfx950 code", device,
+                  prop.gcnArchName);
+    auto *host = new (std::nothrow) lt::DeviceTables;
+    if (!host) return fail(LT_ERROR, "out of host memory");
+    lt::build_device_tables(host);
+    lt::DeviceTables *d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof *host);
+    if (e == hipSuccess) e = hipMemcpy(d, host, sizeof *host, hipMemcpyHostToDevice);
+    delete host;
+    if (e != hipSuccess) return fail(LT_ERROR, "uploading tables failed: %s", hipGetErrorString(e));
+    c.d_tab = d;
+  }
+  *out = c.d_tab;
+  return LT_OK;
+}
+
+struct FindResultHost {
+  int peak_pos;
+  float psr;
+  float peak_value;
+};
+struct SyncStateHost {
+  float m_norm_avg, m_ext_avg;
+};
+struct M0M1Host {
+  int m0, m1;
+  float m0_value, m1_value;
+};
+
+} // namespace
+
+struct lt_pss {
+  int device = 0;
+  int n_id_2 = 10; // invalid until lt_pss_set_N_id_2, like srslte_pss_init
+  hipStream_t stream = nullptr;
+  const lt::DeviceTables *tab = nullptr;
+  float *d_avg = nullptr;
+  lt_cf32 *d_win = nullptr;
+  FindResultHost *d_res = nullptr;
+  float *d_cfo = nullptr;
+  float peak_value = 0.f;
+};
+
+struct lt_cfo {
+  int device = 0;
+  int nsamples = 0;
+  float last_freq = 0.f;
+  hipStream_t stream = nullptr;
+  const lt::DeviceTables *tab = nullptr;
+  lt_cf32 *d_buf = nullptr;
+};
+
+struct lt_sync {
+  int device = 0;
+  int n_id_2 = 10;
+  int cp = LT_CP_NORM;
+  int cp_len = 9;
+  int n_id_1 = 1000; // invalid
+  hipStream_t stream = nullptr;
+  const lt::DeviceTables *tab = nullptr;
+  lt_cf32 *d_in = nullptr;
+  SyncStateHost *d_state = nullptr;
+  int *d_cp = nullptr;
+  M0M1Host *d_res = nullptr;
+};
+
+struct lt_batch {
+  int device = 0;
+  int n_channels = 0;
+  int64_t max_samples = 0;
+  lt_chain_params params{};
+  hipStream_t stream = nullptr;    // own stream
+  hipStream_t last_stream = nullptr;
+  const lt::DeviceTables *tab = nullptr;
+  lt_cf32 *d_iq = nullptr;         // staging for host input, allocated on first use
+  void *d_state = nullptr;
+  lt_record *d_recs = nullptr;
+  int *d_count = nullptr;
+  int rec_cap = 0;
+  lt_cf32 *d_hf = nullptr;
+  int64_t hf_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ran = false;
+  std::vector<lt_record> h_recs;
+  std::vector<int> h_count;
+};
+
+struct lt_decim {
+  int device = 0;
+  int decimation = 1;
+  std::vector<float> taps;
+  float *d_taps = nullptr;
+  hipStream_t stream = nullptr;
+  lt_cf32 *d_x = nullptr, *d_y = nullptr;
+  size_t x_cap = 0, y_cap = 0;
+};
+
+extern "C" {
+
+const char *lt_version(void) { return "ltetrigger_hip 0.1 (gfx950)"; }
+const char *lt_last_error(void) { return g_err; }
+
+int lt_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------ pss
+int lt_pss_init(lt_pss **out, int device, int frame_size, int fft_size)
+{
+  if (!out) return fail(LT_ERROR_INVALID_INPUTS, "null handle pointer");
+  *out = nullptr;
+  if (frame_size != LT_HALF_FRAME_LEN || fft_size != LT_SYMBOL_SZ)
+    return fail(LT_ERROR_INVALID_INPUTS, "only frame_size=9600, fft_size=128 (1.92 Msps) are supported");
+  int rc = use_device(device);
+  if (rc) return rc;
+  lt_pss *q = new (std::nothrow) lt_pss;
+  if (!q) return fail(LT_ERROR, "out of host memory");
+  q->device = device;
+  rc = get_tables(device, &q->tab);
+  if (rc) { delete q; return rc; }
+  hipError_t e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&q->d_avg, sizeof(float) * LT_CONV_LEN);
+  if (e == hipSuccess) e = hipMalloc(&q->d_win, sizeof(lt_cf32) * LT_HALF_FRAME_LEN);
+  if (e == hipSuccess) e = hipMalloc(&q->d_res, sizeof(FindResultHost));
+  if (e == hipSuccess) e = hipMalloc(&q->d_cfo, sizeof(float));
+  if (e == hipSuccess) e = hipMemset(q->d_avg, 0, sizeof(float) * LT_CONV_LEN);
+  if (e != hipSuccess) {
+    lt_pss_free(q);
+    return fail(LT_ERROR, "lt_pss_init: %s", hipGetErrorString(e));
+  }
+  *out = q;
+  return LT_OK;
+}
+
+int lt_pss_set_N_id_2(lt_pss *q, int N_id_2)
+{
+  if (!q || N_id_2 < 0 || N_id_2 > 2) return fail(LT_ERROR_INVALID_INPUTS, "invalid N_id_2 %d", N_id_2);
+  q->n_id_2 = N_id_2;
+  return LT_OK;
+}
+
+void lt_pss_free(lt_pss *q)
+{
+  if (!q) return;
+  (void)hipSetDevice(q->device);
+  if (q->d_avg) (void)hipFree(q->d_avg);
+  if (q->d_win) (void)hipFree(q->d_win);
+  if (q->d_res) (void)hipFree(q->d_res);
+  if (q->d_cfo) (void)hipFree(q->d_cfo);
+  if (q->stream) (void)hipStreamDestroy(q->stream);
+  delete q;
+}
+
+int lt_pss_reset(lt_pss *q)
+{
+  if (!q) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  HIP_TRY(hipSetDevice(q->device));
+  HIP_TRY(hipMemsetAsync(q->d_avg, 0, sizeof(float) * LT_CONV_LEN, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  return LT_OK;
+}
+
+int lt_pss_find_pss(lt_pss *q, const lt_cf32 *in, float *psr)
+{
+  if (!q || !in) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (q->n_id_2 < 0 || q->n_id_2 > 2) return fail(LT_ERROR, "Error finding PSS peak, Must set N_id_2 first");
+  HIP_TRY(hipSetDevice(q->device));
+  HIP_TRY(hipMemcpyAsync(q->d_win, in, sizeof(lt_cf32) * LT_HALF_FRAME_LEN, hipMemcpyHostToDevice, q->stream));
+  HIP_TRY(lt::launch_find(q->d_win, q->d_avg, q->tab, q->n_id_2, q->d_res, q->stream));
+  FindResultHost r;
+  HIP_TRY(hipMemcpyAsync(&r, q->d_res, sizeof r, hipMemcpyDeviceToHost, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  q->peak_value = r.peak_value;
+  if (psr) *psr = r.psr;
+  return r.peak_pos;
+}
+
+int lt_pss_get_peak_value(lt_pss *q, float *v)
+{
+  if (!q || !v) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  *v = q->peak_value;
+  return LT_OK;
+}
+
+int lt_pss_get_avg(lt_pss *q, float *avg)
+{
+  if (!q || !avg) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  HIP_TRY(hipSetDevice(q->device));
+  HIP_TRY(hipMemcpyAsync(avg, q->d_avg, sizeof(float) * LT_CONV_LEN, hipMemcpyDeviceToHost, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  avg[LT_CONV_LEN] = 0.f; // the 9729th entry of conv_output_avg is never written
+  return LT_OK;
+}
+
+int lt_pss_cfo_compute(lt_pss *q, const lt_cf32 *pss_recv, float *cfo)
+{
+  if (!q || !pss_recv || !cfo) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (q->n_id_2 < 0 || q->n_id_2 > 2) return fail(LT_ERROR, "Must set N_id_2 first");
+  HIP_TRY(hipSetDevice(q->device));
+  HIP_TRY(hipMemcpyAsync(q->d_win, pss_recv, sizeof(lt_cf32) * LT_SYMBOL_SZ, hipMemcpyHostToDevice, q->stream));
+  HIP_TRY(lt::launch_cfo_compute(q->d_win, q->tab, q->n_id_2, q->d_cfo, q->stream));
+  HIP_TRY(hipMemcpyAsync(cfo, q->d_cfo, sizeof(float), hipMemcpyDeviceToHost, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  return LT_OK;
+}
+
+// ------------------------------------------------------------------ cfo
+int lt_cfo_init(lt_cfo **out, int device, int nsamples)
+{
+  if (!out || nsamples <= 0) return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  *out = nullptr;
+  int rc = use_device(device);
+  if (rc) return rc;
+  lt_cfo *h = new (std::nothrow) lt_cfo;
+  if (!h) return fail(LT_ERROR, "out of host memory");
+  h->device = device;
+  h->nsamples = nsamples;
+  rc = get_tables(device, &h->tab);
+  if (rc) { delete h; return rc; }
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&h->d_buf, sizeof(lt_cf32) * (size_t)nsamples);
+  if (e != hipSuccess) {
+    lt_cfo_free(h);
+    return fail(LT_ERROR, "lt_cfo_init: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return LT_OK;
+}
+
+void lt_cfo_free(lt_cfo *h)
+{
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->d_buf) (void)hipFree(h->d_buf);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int lt_cfo_set_last_freq(lt_cfo *h, float freq)
+{
+  if (!h) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  h->last_freq = freq; // the phase table is recomputed per call; kept for API parity only
+  return LT_OK;
+}
+
+int lt_cfo_correct(lt_cfo *h, const lt_cf32 *in, lt_cf32 *out, float freq)
+{
+  if (!h || !in || !out) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = sizeof(lt_cf32) * (size_t)h->nsamples;
+  HIP_TRY(hipMemcpyAsync(h->d_buf, in, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(lt::launch_cfo_correct(h->d_buf, h->d_buf, h->nsamples, freq, h->tab, h->stream));
+  HIP_TRY(hipMemcpyAsync(out, h->d_buf, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->last_freq = freq;
+  return LT_OK;
+}
+
+// ------------------------------------------------------------------ sync / sss
+int lt_sync_init(lt_sync **out, int device, int frame_size, int max_offset, int fft_size)
+{
+  if (!out) return fail(LT_ERROR_INVALID_INPUTS, "null handle pointer");
+  *out = nullptr;
+  (void)max_offset; // "set arbitrarily, does it matter?" lib/sss_impl.h:47 -- unused by the path
+  if (frame_size != LT_HALF_FRAME_LEN || fft_size != LT_SYMBOL_SZ)
+    return fail(LT_ERROR_INVALID_INPUTS, "only frame_size=9600, fft_size=128 (1.92 Msps) are supported");
+  int rc = use_device(device);
+  if (rc) return rc;
+  lt_sync *q = new (std::nothrow) lt_sync;
+  if (!q) return fail(LT_ERROR, "out of host memory");
+  q->device = device;
+  rc = get_tables(device, &q->tab);
+  if (rc) { delete q; return rc; }
+  hipError_t e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&q->d_in, sizeof(lt_cf32) * LT_HALF_FRAME_LEN);
+  if (e == hipSuccess) e = hipMalloc(&q->d_state, sizeof(SyncStateHost));
+  if (e == hipSuccess) e = hipMalloc(&q->d_cp, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&q->d_res, sizeof(M0M1Host));
+  if (e == hipSuccess) e = hipMemset(q->d_state, 0, sizeof(SyncStateHost));
+  if (e != hipSuccess) {
+    lt_sync_free(q);
+    return fail(LT_ERROR, "lt_sync_init: %s", hipGetErrorString(e));
+  }
+  *out = q;
+  return LT_OK;
+}
+
+int lt_sync_set_N_id_2(lt_sync *q, int N_id_2)
+{
+  if (!q || N_id_2 < 0 || N_id_2 > 2) return fail(LT_ERROR_INVALID_INPUTS, "invalid N_id_2 %d", N_id_2);
+  q->n_id_2 = N_id_2;
+  return LT_OK;
+}
+
+void lt_sync_free(lt_sync *q)
+{
+  if (!q) return;
+  (void)hipSetDevice(q->device);
+  if (q->d_in) (void)hipFree(q->d_in);
+  if (q->d_state) (void)hipFree(q->d_state);
+  if (q->d_cp) (void)hipFree(q->d_cp);
+  if (q->d_res) (void)hipFree(q->d_res);
+  if (q->stream) (void)hipStreamDestroy(q->stream);
+  delete q;
+}
+
+int lt_sync_reset(lt_sync *q)
+{
+  if (!q) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  HIP_TRY(hipSetDevice(q->device));
+  HIP_TRY(hipMemsetAsync(q->d_state, 0, sizeof(SyncStateHost), q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  return LT_OK;
+}
+
+int lt_sync_detect_cp(lt_sync *q, const lt_cf32 *in, int peak_pos)
+{
+  if (!q || !in || peak_pos < 0 || peak_pos > LT_HALF_FRAME_LEN)
+    return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  HIP_TRY(hipSetDevice(q->device));
+  if (peak_pos > 0)
+    HIP_TRY(hipMemcpyAsync(q->d_in, in, sizeof(lt_cf32) * (size_t)peak_pos, hipMemcpyHostToDevice, q->stream));
+  HIP_TRY(lt::launch_detect_cp(q->d_in, peak_pos, q->d_state, q->d_cp, q->stream));
+  int cp = 0;
+  HIP_TRY(hipMemcpyAsync(&cp, q->d_cp, sizeof cp, hipMemcpyDeviceToHost, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  return cp;
+}
+
+int lt_sync_set_cp(lt_sync *q, int cp)
+{
+  if (!q || (cp != LT_CP_NORM && cp != LT_CP_EXT)) return fail(LT_ERROR_INVALID_INPUTS, "invalid cp");
+  q->cp = cp;
+  q->cp_len = (cp == LT_CP_NORM) ? 9 : 32; // SRSLTE_CP_LEN_NORM(1,128) / SRSLTE_CP_LEN_EXT(128)
+  return LT_OK;
+}
+
+int lt_sync_get_cp_len(lt_sync *q) { return q ? q->cp_len : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
+
+int lt_sync_get_cp_metrics(lt_sync *q, float *n, float *e)
+{
+  if (!q) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  HIP_TRY(hipSetDevice(q->device));
+  SyncStateHost s;
+  HIP_TRY(hipMemcpyAsync(&s, q->d_state, sizeof s, hipMemcpyDeviceToHost, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  if (n) *n = s.m_norm_avg;
+  if (e) *e = s.m_ext_avg;
+  return LT_OK;
+}
+
+int lt_sss_m0m1_partial(lt_sync *q, const lt_cf32 *input, uint32_t *m0, float *m0_value, uint32_t *m1,
+                        float *m1_value)
+{
+  if (!q || !input || !m0 || !m1) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (q->n_id_2 < 0 || q->n_id_2 > 2) return fail(LT_ERROR, "Must set N_id_2 first");
+  HIP_TRY(hipSetDevice(q->device));
+  HIP_TRY(hipMemcpyAsync(q->d_in, input, sizeof(lt_cf32) * LT_SYMBOL_SZ, hipMemcpyHostToDevice, q->stream));
+  HIP_TRY(lt::launch_sss_m0m1(q->d_in, q->tab, q->n_id_2, q->d_res, q->stream));
+  M0M1Host r;
+  HIP_TRY(hipMemcpyAsync(&r, q->d_res, sizeof r, hipMemcpyDeviceToHost, q->stream));
+  HIP_TRY(hipStreamSynchronize(q->stream));
+  *m0 = (uint32_t)r.m0;
+  *m1 = (uint32_t)r.m1;
+  if (m0_value) *m0_value = r.m0_value;
+  if (m1_value) *m1_value = r.m1_value;
+  return LT_OK;
+}
+
+int lt_sss_N_id_1(lt_sync *q, uint32_t m0, uint32_t m1)
+{
+  if (!q) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  // 36.211 Table 6.11.2.1-1 through the zero-defaulted 30x30 table (quirk q5); pure integer
+  // lookup, identical to the device copy the batched kernel uses.
+  static lt::DeviceTables *host_tab = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    host_tab = new lt::DeviceTables;
+    lt::build_device_tables(host_tab);
+  });
+  int n = -1;
+  if (m1 > m0) {
+    if (m0 < 30u && m1 - 1u < 30u) n = host_tab->nid1_table[m0][m1 - 1u];
+  } else {
+    if (m1 < 30u && m0 - 1u < 30u) n = host_tab->nid1_table[m1][m0 - 1u];
+  }
+  if (n >= 0) q->n_id_1 = n;
+  return n;
+}
+
+int lt_sync_get_cell_id(lt_sync *q)
+{
+  if (!q) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  if (q->n_id_2 < 0 || q->n_id_2 > 2 || q->n_id_1 < 0 || q->n_id_1 > 167) return -1;
+  return q->n_id_1 * 3 + q->n_id_2;
+}
+
+// ------------------------------------------------------------------ batch
+int64_t lt_batch_record_capacity(int64_t n_samples)
+{
+  return n_samples / (LT_HALF_FRAME_LEN - LT_SLOT_LEN) + 2;
+}
+
+int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samples,
+                    const lt_chain_params *params)
+{
+  if (!out || n_channels <= 0 || max_samples < LT_HALF_FRAME_LEN || !params)
+    return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  *out = nullptr;
+  if (params->track_after <= 0 || params->track_every < 0)
+    return fail(LT_ERROR_INVALID_INPUTS, "invalid chain parameters");
+  int rc = use_device(device);
+  if (rc) return rc;
+  lt_batch *b = new (std::nothrow) lt_batch;
+  if (!b) return fail(LT_ERROR, "out of host memory");
+  b->device = device;
+  b->n_channels = n_channels;
+  b->max_samples = max_samples;
+  b->params = *params;
+  b->rec_cap = (int)lt_batch_record_capacity(max_samples);
+  rc = get_tables(device, &b->tab);
+  if (rc) { delete b; return rc; }
+  const size_t nchains = (size_t)n_channels * 3;
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&b->d_state, lt::chain_state_bytes() * nchains);
+  if (e == hipSuccess) e = hipMalloc(&b->d_recs, sizeof(lt_record) * nchains * (size_t)b->rec_cap);
+  if (e == hipSuccess) e = hipMalloc(&b->d_count, sizeof(int) * nchains);
+  if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
+  if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e != hipSuccess) {
+    lt_batch_free(b);
+    return fail(LT_ERROR, "lt_batch_create: %s", hipGetErrorString(e));
+  }
+  *out = b;
+  return LT_OK;
+}
+
+void lt_batch_free(lt_batch *b)
+{
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
+  if (b->d_iq) (void)hipFree(b->d_iq);
+  if (b->d_state) (void)hipFree(b->d_state);
+  if (b->d_recs) (void)hipFree(b->d_recs);
+  if (b->d_count) (void)hipFree(b->d_count);
+  if (b->d_hf) (void)hipFree(b->d_hf);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int lt_batch_reset(lt_batch *b)
+{
+  if (!b) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = b->last_stream ? b->last_stream : b->stream;
+  const size_t nchains = (size_t)b->n_channels * 3;
+  HIP_TRY(hipMemsetAsync(b->d_state, 0, lt::chain_state_bytes() * nchains, s));
+  HIP_TRY(hipMemsetAsync(b->d_count, 0, sizeof(int) * nchains, s));
+  return LT_OK;
+}
+
+int lt_batch_set_psr_threshold(lt_batch *b, float threshold)
+{
+  if (!b) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  b->params.psr_threshold = threshold;
+  return LT_OK;
+}
+
+int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain)
+{
+  if (!b || max_per_chain < 0) return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
+  if (b->d_hf) {
+    HIP_TRY(hipFree(b->d_hf));
+    b->d_hf = nullptr;
+  }
+  b->hf_cap = 0;
+  if (max_per_chain > 0) {
+    const size_t bytes = sizeof(lt_cf32) * LT_HALF_FRAME_LEN * (size_t)max_per_chain * (size_t)b->n_channels * 3;
+    HIP_TRY(hipMalloc(&b->d_hf, bytes));
+    b->hf_cap = max_per_chain;
+  }
+  return LT_OK;
+}
+
+int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples, void *hip_stream)
+{
+  if (!b || !iq) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (n_samples < 0 || n_samples > b->max_samples)
+    return fail(LT_ERROR_INVALID_INPUTS, "n_samples %lld exceeds max_samples %lld", (long long)n_samples,
+                (long long)b->max_samples);
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+  const lt_cf32 *d_iq = iq;
+  if (!iq_on_device) {
+    const size_t bytes = sizeof(lt_cf32) * (size_t)b->n_channels * (size_t)n_samples;
+    if (!b->d_iq)
+      HIP_TRY(hipMalloc(&b->d_iq, sizeof(lt_cf32) * (size_t)b->n_channels * (size_t)b->max_samples));
+    if (bytes) HIP_TRY(hipMemcpyAsync(b->d_iq, iq, bytes, hipMemcpyHostToDevice, s));
+    d_iq = b->d_iq;
+  }
+  lt::ChainLaunch L;
+  L.iq = d_iq;
+  L.n_samples = n_samples;
+  L.ch_stride = n_samples;
+  L.n_channels = b->n_channels;
+  L.state = b->d_state;
+  L.recs = b->d_recs;
+  L.rec_cap = b->rec_cap;
+  L.rec_count = b->d_count;
+  L.out_hf = b->d_hf;
+  L.out_cap = (int)b->hf_cap;
+  L.tab = b->tab;
+  L.psr_threshold = b->params.psr_threshold;
+  L.track_after = b->params.track_after;
+  L.track_every = b->params.track_every;
+  HIP_TRY(hipEventRecord(b->ev0, s));
+  HIP_TRY(lt::launch_chain(L, s));
+  HIP_TRY(hipEventRecord(b->ev1, s));
+  b->last_stream = s;
+  b->ran = true;
+  return LT_OK;
+}
+
+int lt_batch_last_kernel_ms(lt_batch *b, float *ms)
+{
+  if (!b || !ms) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (!b->ran) return fail(LT_ERROR, "no run yet");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipEventSynchronize(b->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
+  return LT_OK;
+}
+
+int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts)
+{
+  if (!b || !counts || (cap_per_chain > 0 && !recs)) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (!b->ran) return fail(LT_ERROR, "no run to collect");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = b->last_stream;
+  const size_t nchains = (size_t)b->n_channels * 3;
+  b->h_count.resize(nchains);
+  b->h_recs.resize(nchains * (size_t)b->rec_cap);
+  HIP_TRY(hipMemcpyAsync(b->h_count.data(), b->d_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(b->h_recs.data(), b->d_recs, sizeof(lt_record) * b->h_recs.size(),
+                         hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (size_t c = 0; c < nchains; ++c) {
+    int64_t n = b->h_count[c];
+    counts[c] = n;
+    if (n > cap_per_chain) n = cap_per_chain;
+    if (n > 0)
+      memcpy(recs + c * (size_t)cap_per_chain, b->h_recs.data() + c * (size_t)b->rec_cap,
+             sizeof(lt_record) * (size_t)n);
+  }
+  return LT_OK;
+}
+
+int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, int64_t *count)
+{
+  if (!b || !count || chain < 0 || chain >= b->n_channels * 3) return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  if (!b->d_hf || !b->ran) return fail(LT_ERROR, "half-frame capture not enabled or no run yet");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = b->last_stream;
+  HIP_TRY(hipStreamSynchronize(s));
+  // number of emitted half-frames = records with LT_F_EMITTED in the last run
+  int nrec = 0;
+  HIP_TRY(hipMemcpy(&nrec, b->d_count + chain, sizeof nrec, hipMemcpyDeviceToHost));
+  std::vector<lt_record> r((size_t)nrec);
+  if (nrec)
+    HIP_TRY(hipMemcpy(r.data(), b->d_recs + (size_t)chain * b->rec_cap, sizeof(lt_record) * (size_t)nrec,
+                      hipMemcpyDeviceToHost));
+  int64_t n = 0;
+  for (const lt_record &x : r)
+    if (x.flags & LT_F_EMITTED) n++;
+  if (n > b->hf_cap) n = b->hf_cap;
+  *count = n;
+  if (n > cap) n = cap;
+  if (n > 0 && out)
+    HIP_TRY(hipMemcpy(out, b->d_hf + (size_t)chain * (size_t)b->hf_cap * LT_HALF_FRAME_LEN,
+                      sizeof(lt_cf32) * LT_HALF_FRAME_LEN * (size_t)n, hipMemcpyDeviceToHost));
+  return LT_OK;
+}
+
+// ------------------------------------------------------------------ decimator
+int lt_decim_create(lt_decim **out, int device, int decimation)
+{
+  if (!out || decimation < 2 || decimation > 64) return fail(LT_ERROR_INVALID_INPUTS, "decimation must be in [2,64]");
+  *out = nullptr;
+  int rc = use_device(device);
+  if (rc) return rc;
+  lt_decim *d = new (std::nothrow) lt_decim;
+  if (!d) return fail(LT_ERROR, "out of host memory");
+  d->device = device;
+  d->decimation = decimation;
+  d->taps = lt::decim_design(decimation);
+  hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&d->d_taps, sizeof(float) * d->taps.size());
+  if (e == hipSuccess) e = hipMemcpy(d->d_taps, d->taps.data(), sizeof(float) * d->taps.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    lt_decim_free(d);
+    return fail(LT_ERROR, "lt_decim_create: %s", hipGetErrorString(e));
+  }
+  *out = d;
+  return LT_OK;
+}
+
+void lt_decim_free(lt_decim *d)
+{
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  if (d->d_taps) (void)hipFree(d->d_taps);
+  if (d->d_x) (void)hipFree(d->d_x);
+  if (d->d_y) (void)hipFree(d->d_y);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+int lt_decim_ntaps(lt_decim *d) { return d ? (int)d->taps.size() : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
+
+int lt_decim_get_taps(lt_decim *d, float *taps)
+{
+  if (!d || !taps) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  memcpy(taps, d->taps.data(), sizeof(float) * d->taps.size());
+  return LT_OK;
+}
+
+int lt_decim_run(lt_decim *d, const lt_cf32 *x, lt_cf32 *y, int n_channels, int64_t n_in, int on_device,
+                 void *hip_stream)
+{
+  if (!d || !x || !y || n_channels <= 0 || n_in < 0) return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  HIP_TRY(hipSetDevice(d->device));
+  const int64_t n_out = n_in / d->decimation;
+  if (on_device) {
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : d->stream;
+    HIP_TRY(lt::launch_decim(x, y, n_channels, n_in, d->decimation, d->d_taps, (int)d->taps.size(), s));
+    return LT_OK;
+  }
+  const size_t xb = sizeof(lt_cf32) * (size_t)n_channels * (size_t)n_in;
+  const size_t yb = sizeof(lt_cf32) * (size_t)n_channels * (size_t)n_out;
+  if (xb > d->x_cap) {
+    if (d->d_x) HIP_TRY(hipFree(d->d_x));
+    d->d_x = nullptr; d->x_cap = 0;
+    HIP_TRY(hipMalloc(&d->d_x, xb));
+    d->x_cap = xb;
+  }
+  if (yb > d->y_cap) {
+    if (d->d_y) HIP_TRY(hipFree(d->d_y));
+    d->d_y = nullptr; d->y_cap = 0;
+    HIP_TRY(hipMalloc(&d->d_y, yb ? yb : 8));
+    d->y_cap = yb;
+  }
+  if (xb) HIP_TRY(hipMemcpyAsync(d->d_x, x, xb, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(lt::launch_decim(d->d_x, d->d_y, n_channels, n_in, d->decimation, d->d_taps, (int)d->taps.size(), d->stream));
+  if (yb) HIP_TRY(hipMemcpyAsync(y, d->d_y, yb, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return LT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,472 @@
+// gfx950 kernels of the LTE cell-search hot path.
+//
+//   lt_chain_kernel  -- the product's hot kernel: one persistent workgroup per (channel, N_id_2)
+//                       chain walks the whole capture half-frame by half-frame, running
+//                       pss_impl::general_work (lib/pss_impl.cc:155-223) and, on every emitted
+//                       half-frame, sss_impl::work (lib/sss_impl.cc:83-156), and writes one
+//                       lt_record per call.  IQ is read once from HBM into LDS; the 3 x 65 filter
+//                       taps are wave-uniform scalars; peak / side-lobe reductions are wavefront
+//                       shuffles; the EMA of the lag metric stays in registers.
+//   lt_find_kernel, lt_cfo_*, lt_sync_* -- single-call forms behind the srslte_* shaped C-ABI.
+//   lt_decim_kernel  -- decimating FIR in front of the path.
+#include "lt_device.h"
+
+namespace lt {
+
+struct ChainArgs {
+  const v2f *iq;          // [n_channels][ch_stride]
+  int64_t n_samples;
+  int64_t ch_stride;
+  int n_channels;
+  ChainState *state;      // [n_channels*3], index channel*3 + n_id_2
+  lt_record *recs;        // [n_channels*3][rec_cap]
+  int rec_cap;
+  int *rec_count;         // [n_channels*3]
+  v2f *out_hf;            // nullable: [n_channels*3][out_cap][9600]
+  int out_cap;
+  const DeviceTables *tab;
+  float psr_threshold;
+  int track_after;
+  int track_every;
+};
+
+__global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
+{
+  __shared__ v2f W[kWLen];
+  __shared__ float AVG[kAvgLen];
+  __shared__ v2f S[kSssLen];
+  __shared__ v2f RAW[kSssLen];
+  __shared__ LdsTables ltab;
+  __shared__ float psr_data[kMovingAvgSz];
+  __shared__ float cfo_data[kMovingAvgSz];
+  __shared__ Scratch sc;
+
+  const int tid = threadIdx.x;
+  // blocks c, c + n_channels, c + 2 n_channels are the three roots of channel c: with n_channels a
+  // multiple of 8 they land on the same XCD (round-robin dispatch) and share its L2 copy of the IQ.
+  const int channel = blockIdx.x % a.n_channels;
+  const int n_id_2 = blockIdx.x / a.n_channels;
+  const int chain = channel * 3 + n_id_2;
+  const v2f *__restrict__ x = a.iq + (int64_t)channel * a.ch_stride;
+  const int64_t n = a.n_samples;
+  const DeviceTables *__restrict__ tab = a.tab;
+  const v2f *__restrict__ taps = reinterpret_cast<const v2f *>(tab->pss_taps[n_id_2]);
+  ChainState *st = a.state + chain;
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+
+  // ---- load state
+  float ema[kT];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) ema[t] = st->avg[tid * kT + t];
+  for (int i = tid; i < kMovingAvgSz; i += kThreads) {
+    psr_data[i] = st->psr_data[i];
+    cfo_data[i] = st->cfo_data[i];
+  }
+  for (int i = tid; i < kWPad; i += kThreads) {
+    v2f z = {0.f, 0.f};
+    W[i] = z;
+    W[kWPad + kHalfFrame + i] = z;
+  }
+  if (tid < kAvgLen - kConvLen) AVG[kConvLen + tid] = 0.f;
+  load_lds_tables(ltab, tab, n_id_2);
+  int64_t pos = 0; // every run starts at sample 0 of the capture handed to it
+  int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
+  int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
+  uint32_t psr_i = st->psr_i, cfo_i = st->cfo_i;
+  int n_emits = 0;
+  float psr = st->psr, psr_max = st->psr_max;
+  float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
+  int nrec = 0;
+  __syncthreads();
+
+  while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
+    uint32_t flags = 0;
+    float peak_value = 0.f;
+
+    // ---- lib/pss_impl.cc:163-172
+    if (!is_tracking || timer == 0) {
+      timer = a.track_every;
+      for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+      __syncthreads();
+      const SearchResult r = search_window(W, AVG, ema, taps, sc);
+      peak_pos = r.peak_pos;
+      psr = r.psr;
+      peak_value = r.peak_value;
+      if (tid == 0) psr_data[psr_i % kMovingAvgSz] = psr;
+      psr_i++;
+      flags |= LT_F_SEARCHED;
+    } else {
+      timer--;
+    }
+    const int used_peak_pos = peak_pos;
+
+    // ---- score, lib/pss_impl.cc:174-182 (incr_score :111-127, reset_score :129-152)
+    const bool over = psr > a.psr_threshold;
+    if (over) {
+      if (!(is_tracking && score == a.track_after)) {
+        score++;
+        if (!is_tracking && score == a.track_after) {
+          is_tracking = 1;
+#pragma unroll
+          for (int t = 0; t < kT; ++t) ema[t] = 0.f; // srslte_pss_reset
+        }
+      }
+      flags |= LT_F_OVER;
+    } else if (score != 0) {
+      score = 0;
+      timer = 0;
+      is_tracking = 0;
+#pragma unroll
+      for (int t = 0; t < kT; ++t) ema[t] = 0.f;
+      psr_i = 0;
+      cfo_i = 0;
+      tracking_lost = 1;
+    }
+    if (psr > psr_max) psr_max = psr;
+
+    int64_t out_pos = -1, next_pos;
+    float cfo = 0.f, mean_cfo = 0.f, m0_value = 0.f, m1_value = 0.f;
+    int m0 = -1, m1 = -1, n_id_1 = -1, cell_id = -1;
+
+    if (over || tracking_lost) { // ---- lib/pss_impl.cc:184-214
+      const int frame_start = peak_pos - kSlotLen;
+      peak_pos = kSlotLen;
+      const int64_t hf0 = pos + frame_start;
+      if (hf0 + kHalfFrame > n) break; // quirk q1 normalised: never read past the capture
+      next_pos = hf0 + kHalfFrame;
+      out_pos = hf0;
+      flags |= LT_F_EMITTED;
+      v2f *out = (a.out_hf && n_emits < a.out_cap)
+                     ? a.out_hf + ((int64_t)chain * a.out_cap + n_emits) * kHalfFrame
+                     : nullptr;
+
+      if (is_tracking) {
+        // stage half-frame samples [480, 960) once (coalesced); everything below reads LDS
+        if (tid < kSssLen) RAW[tid] = ld_iq(x, n, hf0 + kSssBase + tid);
+        __syncthreads();
+        // srslte_pss_cfo_compute on the uncorrected PSS symbol, lib/pss_impl.cc:199-201
+        if (tid < 2) {
+          const v2f *sym = RAW + (kSlotLen - kSymbolSz - kSssBase);
+          sc.y[tid] = cfo_half_dot(ltab.taps, tid * 64, [&](int m) { return sym[m]; });
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const float c = cfo_from_halves(sc.y[0], sc.y[1]);
+          cfo_data[cfo_i % kMovingAvgSz] = c;
+          sc.cfo = c;
+          sc.mean_cfo = moving_avg(cfo_data, cfo_i + 1);
+        }
+        __syncthreads();
+        cfo_i++;
+        cfo = sc.cfo;
+        mean_cfo = sc.mean_cfo;
+        // srslte_cfo_correct(out, out, -mean_cfo()/symbol_sz), lib/pss_impl.cc:204
+        const float freq = -mean_cfo / (float)kSymbolSz;
+        const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+        if (tid < kSssLen) S[tid] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + tid, RAW[tid]);
+        if (out)
+          for (int i = tid; i < kHalfFrame; i += kThreads)
+            out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
+        __syncthreads();
+        // srslte_pss_chest (lib/pss_impl.cc:206-209): its output is never consumed -- dropped.
+
+        // ---- sss_impl::work, no tracking_lost tag on this half-frame (lib/sss_impl.cc:102-150)
+        const SssResult s = sss_stage(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
+        flags |= LT_F_SSS_RAN;
+        if (s.cp == LT_CP_EXT) flags |= LT_F_CP_EXT;
+        m0 = s.m0; m1 = s.m1; m0_value = s.m0_value; m1_value = s.m1_value;
+        n_id_1 = s.n_id_1;
+        if (n_id_1 >= 0) {
+          cell_id = 3 * n_id_1 + n_id_2; // srslte_sync_get_cell_id
+          flags |= LT_F_TAG_CELL;
+        }
+      } else {
+        // tracking lost: tag the half-frame (lib/pss_impl.cc:210-214); sss resets on the tag
+        // (lib/sss_impl.cc:91-100)
+        flags |= LT_F_TAG_LOST;
+        tracking_lost = 0;
+        m_norm_avg = 0.f;
+        m_ext_avg = 0.f;
+        if (out)
+          for (int i = tid; i < kHalfFrame; i += kThreads) out[i] = ld_iq(x, n, hf0 + i);
+      }
+      n_emits++;
+    } else {
+      next_pos = pos + kHalfFrame; // lib/pss_impl.cc:217
+    }
+
+    if (is_tracking) flags |= LT_F_TRACKING;
+    if (tid == 0) {
+      lt_record r;
+      r.in_pos = pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
+      r.call_idx = st->n_calls + nrec; r.flags = flags; r.peak_pos = used_peak_pos; r.score = score;
+      r.psr = psr; r.peak_value = peak_value; r.cfo = cfo; r.mean_cfo = mean_cfo;
+      r.m_norm_avg = m_norm_avg; r.m_ext_avg = m_ext_avg; r.m0_value = m0_value;
+      r.m1_value = m1_value; r.m0 = m0; r.m1 = m1; r.n_id_1 = n_id_1; r.cell_id = cell_id;
+      r.psr_max = psr_max; r.timer = timer;
+      recs[nrec] = r;
+    }
+    nrec++;
+    pos = next_pos;
+  }
+
+  // ---- store state
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < kT; ++t) st->avg[tid * kT + t] = ema[t];
+  for (int i = tid; i < kMovingAvgSz; i += kThreads) {
+    st->psr_data[i] = psr_data[i];
+    st->cfo_data[i] = cfo_data[i];
+  }
+  if (tid == 0) {
+    st->pos = pos;
+    st->is_tracking = is_tracking; st->score = score; st->timer = timer;
+    st->tracking_lost = tracking_lost; st->peak_pos = peak_pos;
+    st->psr_i = psr_i; st->cfo_i = cfo_i;
+    st->n_calls += nrec; st->n_emits += n_emits;
+    st->psr = psr; st->psr_max = psr_max;
+    st->m_norm_avg = m_norm_avg; st->m_ext_avg = m_ext_avg;
+    a.rec_count[chain] = nrec;
+  }
+}
+
+// ---------------------------------------------------------------- single-call kernels
+
+struct FindResult {
+  int peak_pos;
+  float psr;
+  float peak_value;
+};
+
+// srslte_pss_find_pss for one handle: window = 9600 device samples, avg = 9728-float EMA state.
+__global__ __launch_bounds__(kThreads) void lt_find_kernel(const v2f *__restrict__ win, float *avg,
+                                                           const DeviceTables *__restrict__ tab,
+                                                           int n_id_2, FindResult *res)
+{
+  __shared__ v2f W[kWLen];
+  __shared__ float AVG[kAvgLen];
+  __shared__ Scratch sc;
+  const int tid = threadIdx.x;
+  float ema[kT];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) ema[t] = avg[tid * kT + t];
+  for (int i = tid; i < kWPad; i += kThreads) {
+    v2f z = {0.f, 0.f};
+    W[i] = z;
+    W[kWPad + kHalfFrame + i] = z;
+  }
+  if (tid < kAvgLen - kConvLen) AVG[kConvLen + tid] = 0.f;
+  for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = win[i];
+  __syncthreads();
+  const v2f *taps = reinterpret_cast<const v2f *>(tab->pss_taps[n_id_2]);
+  const SearchResult r = search_window(W, AVG, ema, taps, sc);
+#pragma unroll
+  for (int t = 0; t < kT; ++t) avg[tid * kT + t] = ema[t];
+  if (tid == 0) {
+    res->peak_pos = r.peak_pos;
+    res->psr = r.psr;
+    res->peak_value = r.peak_value;
+  }
+}
+
+__global__ void lt_cfo_compute_kernel(const v2f *__restrict__ sym, const DeviceTables *__restrict__ tab,
+                                      int n_id_2, float *cfo)
+{
+  __shared__ v2f y[2];
+  const int tid = threadIdx.x;
+  const v2f *taps = reinterpret_cast<const v2f *>(tab->pss_taps[n_id_2]);
+  if (tid < 2) y[tid] = cfo_half_dot(taps, tid * 64, [&](int m) { return sym[m]; });
+  __syncthreads();
+  if (tid == 0) *cfo = cfo_from_halves(y[0], y[1]);
+}
+
+__global__ void lt_cfo_correct_kernel(const v2f *__restrict__ in, v2f *__restrict__ out, int n,
+                                      float freq, const DeviceTables *__restrict__ tab)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+  out[i] = cfo_rotate(tab->cexptab, phase_inc, i, in[i]);
+}
+
+struct SyncState {
+  float m_norm_avg, m_ext_avg;
+};
+
+// srslte_sync_detect_cp with peak_pos = 960 semantics generalised: in = first peak_pos samples.
+__global__ void lt_detect_cp_kernel(const v2f *__restrict__ in, int peak_pos, SyncState *st, int *cp_out)
+{
+  __shared__ float R3[2][3], C3[2][3];
+  const int tid = threadIdx.x;
+  int nsym = peak_pos / (kSymbolSz + 32);
+  if (nsym > 3) nsym = 3;
+  if (nsym <= 0) {
+    if (tid == 0) *cp_out = LT_CP_NORM;
+    return;
+  }
+  if (tid < 6) {
+    const int hyp = tid / 3, sym = tid % 3;
+    const int L = hyp ? 32 : 9;
+    if (sym < nsym) {
+      const int p = peak_pos - nsym * (kSymbolSz + L) + sym * (kSymbolSz + L);
+      cp_term(in + p, L, &R3[hyp][sym], &C3[hyp][sym]);
+    } else {
+      R3[hyp][sym] = 0.f;
+      C3[hyp][sym] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mn = st->m_norm_avg, me = st->m_ext_avg;
+    // nsym is 3 for every peak_pos >= 480, which is all the reference ever passes (slot_length)
+    *cp_out = cp_decide(R3, C3, mn, me);
+    st->m_norm_avg = mn;
+    st->m_ext_avg = me;
+  }
+}
+
+struct M0M1Result {
+  int m0, m1;
+  float m0_value, m1_value;
+};
+
+__global__ void lt_sss_m0m1_kernel(const v2f *__restrict__ sym, const DeviceTables *__restrict__ tab,
+                                   int n_id_2, M0M1Result *res)
+{
+  __shared__ v2f Y[62];
+  __shared__ float corr[32];
+  const int tid = threadIdx.x;
+  if (tid < 62) Y[tid] = sss_dft_bin(sym, tid, tab->dft128_cos, tab->dft128_sin);
+  __syncthreads();
+  if (tid < 31) corr[tid] = sss_corr(Y, 0, tab->sss_c0[n_id_2], nullptr, 0, tab->sss_s, tid);
+  __syncthreads();
+  const int m0 = first_max31(corr);
+  const float v0 = corr[m0];
+  __syncthreads();
+  if (tid < 31) corr[tid] = sss_corr(Y, 1, tab->sss_c1[n_id_2], tab->sss_z, m0 % 8, tab->sss_s, tid);
+  __syncthreads();
+  if (tid == 0) {
+    const int m1 = first_max31(corr);
+    res->m0 = m0; res->m1 = m1; res->m0_value = v0; res->m1_value = corr[m1];
+  }
+}
+
+// ---------------------------------------------------------------- decimating FIR
+// y[c][k] = sum_j taps[j] * x[c][k*D - j].  One thread per output sample; a block stages the
+// (64*D + ntaps) input samples it needs in LDS with coalesced loads.
+constexpr int kDecimOutPerBlock = 256;
+
+__global__ __launch_bounds__(256) void lt_decim_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
+                                                       int64_t n_in, int64_t n_out, int D,
+                                                       const float *__restrict__ taps, int ntaps)
+{
+  extern __shared__ v2f xs[]; // kDecimOutPerBlock*D + ntaps - 1 samples
+  const int c = blockIdx.y;
+  const int64_t k0 = (int64_t)blockIdx.x * kDecimOutPerBlock;
+  const v2f *xc = x + (int64_t)c * n_in;
+  const int64_t first = k0 * D - (ntaps - 1); // oldest input sample needed
+  const int span = kDecimOutPerBlock * D + ntaps - 1;
+  for (int i = threadIdx.x; i < span; i += blockDim.x) xs[i] = ld_iq(xc, n_in, first + i);
+  __syncthreads();
+  const int64_t k = k0 + threadIdx.x;
+  if (k >= n_out) return;
+  // newest sample of output k sits at xs[(ntaps-1) + tid*D]
+  const v2f *p = xs + (ntaps - 1) + threadIdx.x * D;
+  float re = 0.f, im = 0.f;
+  for (int j = 0; j < ntaps; ++j) { // same order and rounding as the oracle: product then add
+    const v2f v = p[-j];
+    const float t = taps[j];
+    re = __fadd_rn(re, __fmul_rn(t, v.x));
+    im = __fadd_rn(im, __fmul_rn(t, v.y));
+  }
+  v2f r = {re, im};
+  y[(int64_t)c * n_out + k] = r;
+}
+
+} // namespace lt
+
+// Host-callable launchers (the C-ABI in lt_api.cpp only sees these).
+#include "lt_launch.h"
+
+namespace lt {
+
+hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
+{
+  ChainArgs a;
+  a.iq = reinterpret_cast<const v2f *>(L.iq);
+  a.n_samples = L.n_samples;
+  a.ch_stride = L.ch_stride;
+  a.n_channels = L.n_channels;
+  a.state = reinterpret_cast<ChainState *>(L.state);
+  a.recs = L.recs;
+  a.rec_cap = L.rec_cap;
+  a.rec_count = L.rec_count;
+  a.out_hf = reinterpret_cast<v2f *>(L.out_hf);
+  a.out_cap = L.out_cap;
+  a.tab = L.tab;
+  a.psr_threshold = L.psr_threshold;
+  a.track_after = L.track_after;
+  a.track_every = L.track_every;
+  hipLaunchKernelGGL(lt_chain_kernel, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+size_t chain_state_bytes() { return sizeof(ChainState); }
+size_t chain_state_avg_offset() { return offsetof(ChainState, avg); }
+
+hipError_t launch_find(const void *win, float *avg, const DeviceTables *tab, int n_id_2, void *res,
+                       hipStream_t stream)
+{
+  hipLaunchKernelGGL(lt_find_kernel, dim3(1), dim3(kThreads), 0, stream,
+                     reinterpret_cast<const v2f *>(win), avg, tab, n_id_2,
+                     reinterpret_cast<FindResult *>(res));
+  return hipGetLastError();
+}
+
+hipError_t launch_cfo_compute(const void *sym, const DeviceTables *tab, int n_id_2, float *cfo,
+                              hipStream_t stream)
+{
+  hipLaunchKernelGGL(lt_cfo_compute_kernel, dim3(1), dim3(64), 0, stream,
+                     reinterpret_cast<const v2f *>(sym), tab, n_id_2, cfo);
+  return hipGetLastError();
+}
+
+hipError_t launch_cfo_correct(const void *in, void *out, int n, float freq, const DeviceTables *tab,
+                              hipStream_t stream)
+{
+  hipLaunchKernelGGL(lt_cfo_correct_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                     reinterpret_cast<const v2f *>(in), reinterpret_cast<v2f *>(out), n, freq, tab);
+  return hipGetLastError();
+}
+
+hipError_t launch_detect_cp(const void *in, int peak_pos, void *sync_state, int *cp_out,
+                            hipStream_t stream)
+{
+  hipLaunchKernelGGL(lt_detect_cp_kernel, dim3(1), dim3(64), 0, stream,
+                     reinterpret_cast<const v2f *>(in), peak_pos,
+                     reinterpret_cast<SyncState *>(sync_state), cp_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2, void *res,
+                           hipStream_t stream)
+{
+  hipLaunchKernelGGL(lt_sss_m0m1_kernel, dim3(1), dim3(64), 0, stream,
+                     reinterpret_cast<const v2f *>(sym), tab, n_id_2,
+                     reinterpret_cast<M0M1Result *>(res));
+  return hipGetLastError();
+}
+
+hipError_t launch_decim(const void *x, void *y, int n_channels, int64_t n_in, int D, const float *taps,
+                        int ntaps, hipStream_t stream)
+{
+  const int64_t n_out = n_in / D;
+  if (n_out <= 0) return hipSuccess;
+  const size_t lds = sizeof(v2f) * (size_t)(kDecimOutPerBlock * D + ntaps - 1);
+  dim3 grid((unsigned)((n_out + kDecimOutPerBlock - 1) / kDecimOutPerBlock), (unsigned)n_channels);
+  hipLaunchKernelGGL(lt_decim_kernel, grid, dim3(256), lds, stream, reinterpret_cast<const v2f *>(x),
+                     reinterpret_cast<v2f *>(y), n_in, n_out, D, taps, ntaps);
+  return hipGetLastError();
+}
+
+} // namespace lt

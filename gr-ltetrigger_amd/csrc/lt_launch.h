@@ -1,0 +1,50 @@
+// Host-visible launch interface of lt_kernels.hip (keeps device types out of the C-ABI layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/ltetrigger_hip.h"
+#include "lt_tables.h"
+
+namespace lt {
+
+struct ChainLaunch {
+  const void *iq;     // device, [n_channels][ch_stride] cf32
+  int64_t n_samples;
+  int64_t ch_stride;
+  int n_channels;
+  void *state;        // device, ChainState[n_channels*3]
+  lt_record *recs;    // device, [n_channels*3][rec_cap]
+  int rec_cap;
+  int *rec_count;     // device, [n_channels*3]
+  void *out_hf;       // device or null, [n_channels*3][out_cap][9600] cf32
+  int out_cap;
+  const DeviceTables *tab; // device
+  float psr_threshold;
+  int track_after;
+  int track_every;
+};
+
+hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream);
+size_t chain_state_bytes();
+size_t chain_state_avg_offset();
+
+// res: device struct {int peak_pos; float psr; float peak_value;}
+hipError_t launch_find(const void *win, float *avg, const DeviceTables *tab, int n_id_2, void *res,
+                       hipStream_t stream);
+hipError_t launch_cfo_compute(const void *sym, const DeviceTables *tab, int n_id_2, float *cfo,
+                              hipStream_t stream);
+hipError_t launch_cfo_correct(const void *in, void *out, int n, float freq, const DeviceTables *tab,
+                              hipStream_t stream);
+// sync_state: device struct {float m_norm_avg, m_ext_avg;}
+hipError_t launch_detect_cp(const void *in, int peak_pos, void *sync_state, int *cp_out,
+                            hipStream_t stream);
+// res: device struct {int m0, m1; float m0_value, m1_value;}
+hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2, void *res,
+                           hipStream_t stream);
+hipError_t launch_decim(const void *x, void *y, int n_channels, int64_t n_in, int D, const float *taps,
+                        int ntaps, hipStream_t stream);
+
+} // namespace lt

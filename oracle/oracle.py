@@ -38,14 +38,34 @@ class ChainParams(C.Structure):
                 ("track_every", C.c_int32)]
 
 
+def _host_tag():
+    """The library is built -march=native: rebuild when the host CPU differs from the builder's."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(flags.encode()).hexdigest()
+
+
 def build(force=False):
     src = os.path.join(_HERE, "lte_oracle.c")
     hdr = os.path.join(_HERE, "lte_oracle.h")
-    if (not force and os.path.exists(_LIB_PATH)
+    tag_path = _LIB_PATH + ".host"
+    tag = _host_tag()
+    try:
+        with open(tag_path) as f:
+            same_host = f.read().strip() == tag
+    except OSError:
+        same_host = False
+    if (not force and same_host and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "liblte_oracle.so"],
                           stdout=subprocess.DEVNULL)
+    with open(tag_path, "w") as f:
+        f.write(tag)
     return _LIB_PATH
 
 

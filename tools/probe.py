@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Kernel-time probe for lt_chain_kernel: pure search (noise only) vs the bench mix."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mode", default="noise", choices=["noise", "clean", "mix"])
+    args = ap.parse_args()
+    import torch
+    import ltetrigger_amd as lt
+    import bench
+    dev = torch.device("cuda", 0)
+    n = int(args.seconds * 1_920_000)
+    frames = bench.base_frames(lt)
+    if args.mode == "noise":
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        iq = torch.view_as_complex(torch.randn((args.channels, n, 2), generator=g, device=dev) * 0.5)
+    elif args.mode == "clean":
+        iq, _ = bench.make_channels(torch, frames, args.channels, n, 0, 100.0, dev)
+        for c in range(7, args.channels, 8):  # make every channel carry a cell
+            iq[c] = iq[c - 1]
+    else:
+        iq, _ = bench.make_channels(torch, frames, args.channels, n, 0, 20.0, dev)
+    iqr = torch.view_as_real(iq).contiguous()
+    torch.cuda.synchronize()
+    b = lt.Batch(args.channels, n)
+    s = torch.cuda.Stream(device=dev)
+    ms = []
+    for _ in range(args.reps):
+        b.reset()
+        b.run_device(iqr.data_ptr(), n, s.cuda_stream)
+        ms.append(b.last_kernel_ms())
+    recs = b.collect()
+    nsearch = sum(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
+    nemit_tr = sum(int((((r["flags"] & lt.F_SSS_RAN) != 0)).sum()) for r in recs)
+    per_chain_search = max(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
+    k = float(np.median(ms))
+    print(f"mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
+          f"searches total {nsearch} (max/chain {per_chain_search}), tracked emits {nemit_tr}; "
+          f"{args.channels * n / k / 1e6:.1f} Gsamp/s; {k * 1e3 / max(per_chain_search, 1):.2f} us per window of the busiest chain")
+
+
+if __name__ == "__main__":
+    main()
