@@ -146,6 +146,7 @@ struct lt_batch {
   int64_t hf_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ran = false;
+  int ablate = 0;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
 };
@@ -588,6 +589,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   L.psr_threshold = b->params.psr_threshold;
   L.track_after = b->params.track_after;
   L.track_every = b->params.track_every;
+  L.ablate = b->ablate;
   HIP_TRY(hipEventRecord(b->ev0, s));
   HIP_TRY(lt::launch_chain(L, s));
   HIP_TRY(hipEventRecord(b->ev1, s));
@@ -653,6 +655,15 @@ int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, i
   if (n > 0 && out)
     HIP_TRY(hipMemcpy(out, b->d_hf + (size_t)chain * (size_t)b->hf_cap * LT_HALF_FRAME_LEN,
                       sizeof(lt_cf32) * LT_HALF_FRAME_LEN * (size_t)n, hipMemcpyDeviceToHost));
+  return LT_OK;
+}
+
+// Diagnostics only (tools/probe.py): ablate parts of the chain kernel to time the rest.
+// Not declared in the public header; results are meaningless while a flag is set.
+int lt_debug_set_ablation(lt_batch *b, int flags)
+{
+  if (!b) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
+  b->ablate = flags;
   return LT_OK;
 }
 

@@ -141,13 +141,34 @@ __device__ __forceinline__ void argmax_combine(float &v, int &i, float ov, int o
 // arg-max, main-lobe walk, peak-to-side-lobe ratio (call site lib/pss_impl.cc:165).
 // `ema` is this thread's slice of conv_output_avg.  Contains __syncthreads().
 __device__ __forceinline__ SearchResult search_window(const v2f *W, float *AVG, float ema[kT],
-                                                     const v2f *__restrict__ taps, Scratch &sc)
+                                                     const v2f *__restrict__ taps, Scratch &sc,
+                                                     int ablate)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = tid * kT;
 
   v2f acc[kT];
-  conv19(W + kWPad + n0, taps, acc);
+  if (ablate & 2) { // diagnostics: no matched filter
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[t] = W[kWPad + n0 + t];
+  } else {
+    conv19(W + kWPad + n0, taps, acc);
+  }
+  if (ablate & 4) { // diagnostics: no reductions
+    SearchResult r0;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      ema[t] = acc[t].x * acc[t].x + acc[t].y * acc[t].y;
+      s += ema[t];
+    }
+    AVG[n0] = s;
+    __syncthreads();
+    r0.peak_pos = __builtin_amdgcn_readfirstlane((int)AVG[4] & 1023);
+    r0.peak_value = 1.f;
+    r0.psr = 1.f;
+    return r0;
+  }
 
   // |conv|^2, EMA with three roundings like srsLTE's three vector passes, local first-maximum
   float bv = -FLT_MAX;

@@ -28,6 +28,7 @@ struct ChainArgs {
   float psr_threshold;
   int track_after;
   int track_every;
+  int ablate;             // diagnostics only (tools/probe.py): 1 = skip the window load
 };
 
 __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
@@ -86,9 +87,10 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
     // ---- lib/pss_impl.cc:163-172
     if (!is_tracking || timer == 0) {
       timer = a.track_every;
-      for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+      if (!(a.ablate & 1))
+        for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
       __syncthreads();
-      const SearchResult r = search_window(W, AVG, ema, taps, sc);
+      const SearchResult r = search_window(W, AVG, ema, taps, sc, a.ablate);
       peak_pos = r.peak_pos;
       psr = r.psr;
       peak_value = r.peak_value;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void lt_find_kernel(const v2f *__restrict
   for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = win[i];
   __syncthreads();
   const v2f *taps = reinterpret_cast<const v2f *>(tab->pss_taps[n_id_2]);
-  const SearchResult r = search_window(W, AVG, ema, taps, sc);
+  const SearchResult r = search_window(W, AVG, ema, taps, sc, 0);
 #pragma unroll
   for (int t = 0; t < kT; ++t) avg[tid * kT + t] = ema[t];
   if (tid == 0) {
@@ -407,6 +409,7 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
   a.psr_threshold = L.psr_threshold;
   a.track_after = L.track_after;
   a.track_every = L.track_every;
+  a.ablate = L.ablate;
   hipLaunchKernelGGL(lt_chain_kernel, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }

@@ -25,6 +25,7 @@ struct ChainLaunch {
   float psr_threshold;
   int track_after;
   int track_every;
+  int ablate = 0; // diagnostics only
 };
 
 hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream);

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mode", default="noise", choices=["noise", "clean", "mix"])
+    ap.add_argument("--ablate", type=int, default=0, help="1 no window load, 2 no conv, 4 no reductions")
     args = ap.parse_args()
     import torch
     import ltetrigger_amd as lt
@@ -35,6 +36,9 @@ def main():
     iqr = torch.view_as_real(iq).contiguous()
     torch.cuda.synchronize()
     b = lt.Batch(args.channels, n)
+    if args.ablate:
+        import ctypes
+        lt.lib().lt_debug_set_ablation(b._h, ctypes.c_int(args.ablate))
     s = torch.cuda.Stream(device=dev)
     ms = []
     for _ in range(args.reps):
@@ -46,7 +50,7 @@ def main():
     nemit_tr = sum(int((((r["flags"] & lt.F_SSS_RAN) != 0)).sum()) for r in recs)
     per_chain_search = max(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
     k = float(np.median(ms))
-    print(f"mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
+    print(f"ablate={args.ablate} mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
           f"searches total {nsearch} (max/chain {per_chain_search}), tracked emits {nemit_tr}; "
           f"{args.channels * n / k / 1e6:.1f} Gsamp/s; {k * 1e3 / max(per_chain_search, 1):.2f} us per window of the busiest chain")
 
