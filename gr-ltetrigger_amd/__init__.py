@@ -10,3 +10,7 @@ from ._binding import (  # noqa: F401
     HALF_FRAME, SLOT, SYMBOL_SZ, CONV_LEN, NLAGS, CP_NORM, CP_EXT,
     last_error, lib, record_capacity,
 )
+from . import host  # noqa: E402,F401
+from .host import TopBlock, decode_mib  # noqa: E402,F401
+from .downlink_trigger_c import downlink_trigger_c, MIN_PSR_THRESHOLD  # noqa: E402,F401
+from .batch_trigger import BatchTrigger  # noqa: E402,F401
