@@ -108,10 +108,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    from ltetrigger_amd import sharding
     n_ch = args.channels
     n = int(round(args.seconds * FS))
     frames = base_frames(lt)
-    iq, expect = make_channels(torch, frames, n_ch, n, rank * n_ch, args.snr_db, dev)
+    my_channels = sharding.channel_range(rank, world, n_ch)
+    iq, expect = make_channels(torch, frames, n_ch, n, my_channels[0], args.snr_db, dev)
     iq_real = torch.view_as_real(iq)
     assert iq_real.is_contiguous()
     torch.cuda.synchronize()
@@ -149,10 +151,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = sharding.max_over_ranks(dist, torch, elapsed, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
 
     # correctness of what was timed: cell_id match on this rank's channels
@@ -160,14 +159,11 @@ def main():
     found = cells_found(lt, recs, n_ch)
     ok = sum(1 for c in range(n_ch)
              if found[c] == (set() if expect[c] < 0 else {int(expect[c])}))
-    match = torch.tensor([ok, n_ch], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(match, op=dist.ReduceOp.SUM)
-    match_rate = float(match[0].item() / match[1].item())
+    ok_sum, ch_sum = sharding.sum_over_ranks(dist, torch, [ok, n_ch], dev)
+    match_rate = ok_sum / ch_sum
 
     if rank == 0:
-        total_samples = float(world) * n_ch * n * args.steps
-        value = total_samples / elapsed / 1e6
+        value = sharding.aggregate_msamp_per_s(world, n_ch, n, args.steps, elapsed)
         achieved = ALGO_BYTES_PER_SAMPLE * n_ch * n / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -14,3 +14,4 @@ from . import host  # noqa: E402,F401
 from .host import TopBlock, decode_mib  # noqa: E402,F401
 from .downlink_trigger_c import downlink_trigger_c, MIN_PSR_THRESHOLD  # noqa: E402,F401
 from .batch_trigger import BatchTrigger  # noqa: E402,F401
+from . import sharding  # noqa: E402,F401
