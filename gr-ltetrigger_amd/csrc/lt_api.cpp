@@ -147,6 +147,7 @@ struct lt_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ran = false;
   int ablate = 0;
+  unsigned long long *d_prof = nullptr;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
 };
@@ -516,6 +517,7 @@ void lt_batch_free(lt_batch *b)
   if (b->d_recs) (void)hipFree(b->d_recs);
   if (b->d_count) (void)hipFree(b->d_count);
   if (b->d_hf) (void)hipFree(b->d_hf);
+  if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -590,6 +592,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   L.track_after = b->params.track_after;
   L.track_every = b->params.track_every;
   L.ablate = b->ablate;
+  L.prof = b->d_prof;
   HIP_TRY(hipEventRecord(b->ev0, s));
   HIP_TRY(lt::launch_chain(L, s));
   HIP_TRY(hipEventRecord(b->ev1, s));
@@ -664,6 +667,22 @@ int lt_debug_set_ablation(lt_batch *b, int flags)
 {
   if (!b) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
   b->ablate = flags;
+  if ((flags & 8) && !b->d_prof) {
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t bytes = (size_t)b->n_channels * 3 * 24 * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc(&b->d_prof, bytes));
+    HIP_TRY(hipMemset(b->d_prof, 0, bytes));
+  }
+  return LT_OK;
+}
+
+// Diagnostics only: shader-clock sums per phase, [n_channels*3][16], of the last run (flag 8).
+int lt_debug_get_profile(lt_batch *b, unsigned long long *out)
+{
+  if (!b || !b->d_prof) return fail(LT_ERROR_INVALID_INPUTS, "profiling not enabled");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
+  HIP_TRY(hipMemcpy(out, b->d_prof, (size_t)b->n_channels * 3 * 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return LT_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <cstdint>
 
 #include "../../include/ltetrigger_hip.h"
+#include "lt_fft.h"
 #include "lt_tables.h"
 
 namespace lt {
@@ -27,11 +28,15 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kT = 19;                              // lags per thread
 constexpr int kWPad = 128;                          // zero samples in front of the window in LDS
-constexpr int kWLen = kWPad + kHalfFrame + 128;     // 9856 samples = 78848 B
+constexpr int kWLen = 8 * fft::kScratch;             // 10240 samples = 81920 B: window + zero pads; 8 wave-private FFT scratch areas
 constexpr int kAvgLen = kConvLen + 4;               // EMA mirror in LDS, [9728] is the always-zero lag
 constexpr int kSssBase = 480;                       // first half-frame sample the sss stage touches
 constexpr int kSssLen = kSlotLen - kSssBase;        // 480 samples [480, 960)
+constexpr int kBlkValid = fft::kN - (kSymbolSz - 1);  // 897 valid lags per 1024-point overlap-save block
+constexpr int kBlocks = (kConvLen + kBlkValid - 1) / kBlkValid; // 11
 static_assert(kThreads * kT == kConvLen, "lag tiling must cover the convolution exactly");
+static_assert(kWPad + (kBlocks - 1) * kBlkValid - (kSymbolSz - 1) + fft::kN <= kWLen, "window buffer too short");
+static_assert(kBlocks <= 2 * kWaves, "two overlap-save rounds must cover the window");
 
 // Persistent state of one chain (pss_impl + sss_impl members, lib/pss_impl.h:41-81,
 // lib/sss_impl.h:42-44), kept in HBM between launches.
@@ -58,17 +63,11 @@ struct ChainState {
 
 // LDS scratch for block reductions and the sss stage.
 struct Scratch {
-  float am_v[kWaves];
-  int am_i[kWaves];
-  int ub[kWaves];
-  int lb[kWaves];
-  float sl[kWaves];
-  float sr[kWaves];
-  v2f y[2];
-  float cfo, mean_cfo, freq;
-  float cpR[2][3], cpC[2][3];
+  float tmax[kThreads]; // per-thread maximum of the EMA over its valid lags
+  int tidx[kThreads];   // lag of that maximum
+  v2f Yp[62][8];   // SSS DFT partial sums [bin][n mod 8]
   v2f Y[62];
-  float corr[32];
+  float cfo, mean_cfo; // wave 0 -> everyone
 };
 
 struct SearchResult {
@@ -137,46 +136,158 @@ __device__ __forceinline__ void argmax_combine(float &v, int &i, float ov, int o
   }
 }
 
+// ---- wavefront reductions on the VALU cross-lane path (DPP row rotates + 4 readlanes) instead of
+// ds_bpermute: every lane of a 16-lane row ends up with the row's result, the four rows are then
+// combined through scalar registers, so the result is wave-uniform.
+template <int kCtrl> __device__ __forceinline__ int dpp_i(int v)
+{
+  return __builtin_amdgcn_update_dpp(v, v, kCtrl, 0xf, 0xf, false);
+}
+#define LT_ROW_ALLREDUCE(v, OP)                 \
+  v = OP(v, dpp_i<0x128>(v)); /* row_ror:8 */  \
+  v = OP(v, dpp_i<0x124>(v)); /* row_ror:4 */  \
+  v = OP(v, dpp_i<0x122>(v)); /* row_ror:2 */  \
+  v = OP(v, dpp_i<0x121>(v)); /* row_ror:1 */
+
+__device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
+// max of non-NaN floats >= -FLT_MAX, through their ordered bit patterns is not possible for negative
+// values, so compare as floats on reinterpreted lanes
+__device__ __forceinline__ int fmax_bits_(int a, int b) { return __int_as_float(a) >= __int_as_float(b) ? a : b; }
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+  LT_ROW_ALLREDUCE(v, imin_)
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return imin_(imin_(a, b), imin_(c, d));
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+  LT_ROW_ALLREDUCE(v, imax_)
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return imax_(imax_(a, b), imax_(c, d));
+}
+// maximum of floats none of which is NaN (callers pass -FLT_MAX for "nothing")
+__device__ __forceinline__ float wave_max_f(float f)
+{
+  int v = __float_as_int(f);
+  LT_ROW_ALLREDUCE(v, fmax_bits_)
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return __int_as_float(fmax_bits_(fmax_bits_(a, b), fmax_bits_(c, d)));
+}
+
 // srslte_pss_find_pss on the window held in W (LDS, zero padded): lag metric, EMA(0.2),
 // arg-max, main-lobe walk, peak-to-side-lobe ratio (call site lib/pss_impl.cc:165).
 // `ema` is this thread's slice of conv_output_avg.  Contains __syncthreads().
-__device__ __forceinline__ SearchResult search_window(const v2f *W, float *AVG, float ema[kT],
-                                                     const v2f *__restrict__ taps, Scratch &sc,
-                                                     int ablate)
+// Overlap-save matched filter: |conv[lag]|^2 for all 9728 lags of the window in W, written to
+// `metric` (LDS).  Block b (1024 samples starting 127 before lag 897 b) is transformed by one
+// wave: FFT-1024, multiply by the filter spectrum, inverse FFT (as conj(FFT(conj(.)))), keep the
+// 897 alias-free outputs.  Waves 0..2 take a second block (11 blocks, 8 waves).  The window
+// buffer doubles as the FFT scratch once every wave holds its inputs in registers, so the call
+// contains two __syncthreads(); W is garbage afterwards, `metric` complete.
+__device__ __forceinline__ void ols_block(int lane, int b, fft::c32 v[16], const fft::c32 *tw, const fft::c32 *spec,
+                                          fft::c32 *scr, float *metric)
 {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  fft::phase_a(lane, v, tw, scr);
+  fft::phase_b(lane, v, tw, scr, scr);
+  fft::phase_c(lane, v, scr);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fft::conj(fft::cmul(v[r], spec[r * 64 + lane]));
+  fft::scatter_natural(lane, v, scr);
+  fft::gather_strided(lane, v, scr);
+  fft::phase_a(lane, v, tw, scr);
+  fft::phase_b(lane, v, tw, scr, scr);
+  fft::phase_c(lane, v, scr);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = fft::out_index(lane, r);
+    const int lag = b * kBlkValid + i - (kSymbolSz - 1);
+    if (i >= kSymbolSz - 1 && lag < kConvLen)
+      metric[lag] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+  }
+}
+
+__device__ __forceinline__ void conv_metric_fft(v2f *W, float *metric, const v2f *tw, const v2f *spec)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  fft::c32 xa[16], xb[16];
+  const int b0 = wave, b1 = wave + kWaves;
+  {
+    const v2f *p = W + kWPad + b0 * kBlkValid - (kSymbolSz - 1) + lane;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) xa[n1] = p[64 * n1];
+  }
+  if (b1 < kBlocks) {
+    const v2f *p = W + kWPad + b1 * kBlkValid - (kSymbolSz - 1) + lane;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) xb[n1] = p[64 * n1];
+  }
+  __syncthreads(); // every wave holds its inputs: W may now be overwritten
+  fft::c32 *scr = W + wave * fft::kScratch;
+  ols_block(lane, b0, xa, tw, spec, scr, metric);
+  if (b1 < kBlocks) ols_block(lane, b1, xb, tw, spec, scr, metric);
+  __syncthreads(); // metric[] complete
+}
+
+#define LT_STAMP(i)                                              \
+  if (prof) {                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    prof[i] += t_ - t_prev;                                      \
+    t_prev = t_;                                                 \
+  }
+// Part 1 (search_front): matched filter, EMA, LDS mirror, ends with the block-wide barrier; after it
+// the window buffer W is no longer read.  Part 2 (search_tail): arg-max, walk, side lobes, PSR.
+struct FilterLds {
+  const v2f *tw;   // FFT twiddles [16][64] in LDS
+  const v2f *spec; // filter spectrum in wave-FFT register layout [16][64] in LDS
+};
+
+__device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
+                                             const v2f *__restrict__ taps, const FilterLds &fl, Scratch &sc,
+                                             int ablate, unsigned long long *prof = nullptr)
+{
+  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+  const int tid = threadIdx.x;
   const int n0 = tid * kT;
 
-  v2f acc[kT];
+  // lag metric |conv|^2 of this thread's 19 lags
+  float met[kT];
   if (ablate & 2) { // diagnostics: no matched filter
 #pragma unroll
-    for (int t = 0; t < kT; ++t) acc[t] = W[kWPad + n0 + t];
-  } else {
+    for (int t = 0; t < kT; ++t) met[t] = W[kWPad + n0 + t].x;
+  } else if (ablate & 16) { // direct-form reference path (folded 128-tap FIR), kept for A/B checks
+    v2f acc[kT];
     conv19(W + kWPad + n0, taps, acc);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) met[t] = __fadd_rn(__fmul_rn(acc[t].x, acc[t].x), __fmul_rn(acc[t].y, acc[t].y));
+  } else {
+    conv_metric_fft(W, AVG, fl.tw, fl.spec); // AVG doubles as the staging area of the metric
+#pragma unroll
+    for (int t = 0; t < kT; ++t) met[t] = AVG[n0 + t];
   }
   if (ablate & 4) { // diagnostics: no reductions
-    SearchResult r0;
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
-      ema[t] = acc[t].x * acc[t].x + acc[t].y * acc[t].y;
+      ema[t] = met[t];
       s += ema[t];
     }
     AVG[n0] = s;
     __syncthreads();
-    r0.peak_pos = __builtin_amdgcn_readfirstlane((int)AVG[4] & 1023);
-    r0.peak_value = 1.f;
-    r0.psr = 1.f;
-    return r0;
+    return;
   }
 
+  LT_STAMP(0) // matched filter
   // |conv|^2, EMA with three roundings like srsLTE's three vector passes, local first-maximum
   float bv = -FLT_MAX;
   int bi = INT_MAX;
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
     const int lag = n0 + t;
-    const float a = __fadd_rn(__fmul_rn(acc[t].x, acc[t].x), __fmul_rn(acc[t].y, acc[t].y));
+    const float a = met[t];
     if (lag < kNLags) {
       ema[t] = __fadd_rn(__fmul_rn(a, 0.2f), __fmul_rn(ema[t], 1.0f - 0.2f));
       if (ema[t] > bv) {
@@ -186,100 +297,138 @@ __device__ __forceinline__ SearchResult search_window(const v2f *W, float *AVG, 
     }
     AVG[lag] = ema[t];
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(bv, off);
-    const int oi = __shfl_xor(bi, off);
-    argmax_combine(bv, bi, ov, oi);
+  sc.tmax[tid] = bv; // per-thread maximum over its 19 lags (valid lags only) and where it sits
+  sc.tidx[tid] = bi;
+  LT_STAMP(1) // EMA + LDS mirror
+  __syncthreads(); // the only block-wide synchronisation of the search: AVG, tmax, tidx are visible
+  LT_STAMP(2) // barrier wait
+}
+
+__device__ __forceinline__ SearchResult search_tail(const float *AVG, const Scratch &sc, int ablate,
+                                                   unsigned long long *prof = nullptr)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+  if (ablate & 4) {
+    SearchResult r0;
+    r0.peak_pos = __builtin_amdgcn_readfirstlane((int)AVG[4] & 1023);
+    r0.peak_value = 1.f;
+    r0.psr = 1.f;
+    return r0;
   }
-  if (lane == 0) {
-    sc.am_v[wave] = bv;
-    sc.am_i[wave] = bi;
-  }
-  __syncthreads(); // AVG and the per-wave maxima are visible
-  bv = sc.am_v[0];
-  bi = sc.am_i[0];
+  // Every wave redundantly derives the same (wave-uniform) results from LDS, so no further
+  // barrier is needed to broadcast them.
+  // ---- arg-max: first maximum = largest value, smallest lag among equals
+  float bv = -FLT_MAX;
+  int bi = INT_MAX;
 #pragma unroll
-  for (int w = 1; w < kWaves; ++w) argmax_combine(bv, bi, sc.am_v[w], sc.am_i[w]);
+  for (int k = 0; k < kThreads / 64; ++k) argmax_combine(bv, bi, sc.tmax[lane + 64 * k], sc.tidx[lane + 64 * k]);
+  {
+    const float wv = wave_max_f(bv);
+    bi = wave_min_i(bv == wv ? bi : INT_MAX);
+    bv = wv;
+  }
   const int peak = (bi == INT_MAX) ? 0 : bi; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
   const float peak_value = AVG[peak];
+  LT_STAMP(3) // arg-max
 
-  // main-lobe walk, both directions at once:
+  // ---- main-lobe walk, 64 lags per step in each direction:
   //   pl_ub = first u >= peak+1 with !(avg[u+1] <= avg[u]) or u >= 9727
   //   pl_lb = last  l <= peak-1 with !(avg[l-1] <= avg[l]) or l <= 1      (0 when peak <= 2)
-  int ub = INT_MAX, lb = -1;
-  {
-    const float nxt = AVG[n0 + kT];
-    const float prv = (n0 > 0) ? AVG[n0 - 1] : 0.f;
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      const int u = n0 + t;
-      const float cur = ema[t];
-      const float up = (t < kT - 1) ? ema[t + 1] : nxt;
-      const float dn = (t > 0) ? ema[t - 1] : prv;
-      if (u > peak && (!(up <= cur) || u >= kConvLen - 1)) ub = min(ub, u);
-      if (peak > 2 && u < peak && u >= 1 && (!(dn <= cur) || u <= 1)) lb = max(lb, u);
+  int pl_ub = 0, pl_lb = 0;
+  for (int base = peak + 1;; base += 64) {
+    const int u = base + lane;
+    bool stop = false;
+    if (u <= kConvLen - 1) stop = !(AVG[u + 1] <= AVG[u]) || u >= kConvLen - 1;
+    const unsigned long long m = __ballot(stop);
+    if (m) {
+      pl_ub = base + __builtin_ctzll(m);
+      break;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    ub = min(ub, __shfl_xor(ub, off));
-    lb = max(lb, __shfl_xor(lb, off));
+  if (peak > 2) {
+    for (int base = peak - 1;; base -= 64) {
+      const int u = base - lane;
+      bool stop = false;
+      if (u >= 1) stop = !(AVG[u - 1] <= AVG[u]) || u <= 1;
+      const unsigned long long m = __ballot(stop);
+      if (m) {
+        pl_lb = base - __builtin_ctzll(m);
+        break;
+      }
+    }
   }
-  if (lane == 0) {
-    sc.ub[wave] = ub;
-    sc.lb[wave] = lb;
-  }
-  __syncthreads();
-  ub = sc.ub[0];
-  lb = sc.lb[0];
-#pragma unroll
-  for (int w = 1; w < kWaves; ++w) {
-    ub = min(ub, sc.ub[w]);
-    lb = max(lb, sc.lb[w]);
-  }
-  const int pl_ub = ub;
-  const int pl_lb = (peak > 2) ? lb : 0;
 
-  // side lobes: max over [0, pl_lb) and over [pl_ub, 9726)
+  LT_STAMP(4) // walk
+  // ---- side lobes: max over [0, pl_lb) and over [pl_ub, 9726).  Threads whose 19 lags lie
+  // entirely on one side contribute their stored maximum; the two threads cut by the lobe
+  // contribute their outside elements one by one.
+  const int tL = pl_lb / kT, tU = pl_ub / kT;
   float sl = -FLT_MAX, sr = -FLT_MAX;
 #pragma unroll
-  for (int t = 0; t < kT; ++t) {
-    const int u = n0 + t;
-    if (u < pl_lb && ema[t] > sl) sl = ema[t];
-    if (u >= pl_ub && u < kNLags && ema[t] > sr) sr = ema[t];
+  for (int k = 0; k < kThreads / 64; ++k) {
+    const int t = lane + 64 * k;
+    const float v = sc.tmax[t];
+    if (t < tL && v > sl) sl = v;
+    if (t > tU && v > sr) sr = v;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sl = fmaxf(sl, __shfl_xor(sl, off));
-    sr = fmaxf(sr, __shfl_xor(sr, off));
+  if (lane < kT) {
+    const int u = tL * kT + lane;
+    if (u < pl_lb) {
+      const float v = AVG[u];
+      if (v > sl) sl = v;
+    }
+  } else if (lane < 2 * kT) {
+    const int u = pl_ub + (lane - kT);
+    if (u < (tU + 1) * kT && u < kNLags) {
+      const float v = AVG[u];
+      if (v > sr) sr = v;
+    }
   }
-  if (lane == 0) {
-    sc.sl[wave] = sl;
-    sc.sr[wave] = sr;
-  }
-  __syncthreads();
-  sl = sc.sl[0];
-  sr = sc.sr[0];
-#pragma unroll
-  for (int w = 1; w < kWaves; ++w) {
-    sl = fmaxf(sl, sc.sl[w]);
-    sr = fmaxf(sr, sc.sr[w]);
-  }
+  sl = wave_max_f(sl);
+  sr = wave_max_f(sr);
   // an empty range makes srslte_vec_max_fi return index 0 of that range
   if (pl_lb == 0) sl = AVG[0];
   if (kNLags - pl_ub <= 0) sr = AVG[pl_ub];
   const float side = sl > sr ? sl : sr;
 
-  // every thread holds the same values; pin them to scalar registers
+  LT_STAMP(5) // side lobes
+  // wave-uniform values: pin them to scalar registers
   SearchResult r;
   r.peak_pos = __builtin_amdgcn_readfirstlane(peak);
   r.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value)));
   r.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value / side)));
   return r;
 }
+#undef LT_STAMP
 
-// ---- pieces of the tracked-emit path, each evaluated in the oracle's operation order ----
+__device__ __forceinline__ SearchResult search_window(v2f *W, float *AVG, float ema[kT],
+                                                     const v2f *__restrict__ taps, const FilterLds &fl,
+                                                     Scratch &sc, int ablate)
+{
+  search_front(W, AVG, ema, taps, fl, sc, ablate);
+  return search_tail(AVG, sc, ablate);
+}
+
+// copy the FFT twiddles and the filter spectrum of one root into LDS (2 x 8 KB)
+__device__ __forceinline__ void load_filter_lds(v2f *tw, v2f *spec, const DeviceTables *__restrict__ tab, int n_id_2)
+{
+  for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) {
+    tw[i] = v2f{tab->fft_tw[i].re, tab->fft_tw[i].im};
+    spec[i] = v2f{tab->pss_spec[n_id_2][i].re, tab->pss_spec[n_id_2][i].im};
+  }
+}
+
+// ---- pieces of the tracked-emit path.  Every sum is evaluated in the oracle's operation order
+// (interleaved partial sums like the SIMD dot products of srsLTE, combined pairwise), so the
+// results are bit-exact against it.  The *_wave functions are executed by every lane of a wave,
+// read their inputs from LDS, exchange partial results with v_readlane and return wave-uniform
+// values: several waves can run them redundantly instead of waiting on a broadcast.
+
+__device__ __forceinline__ float rlane(float v, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 
 __device__ __forceinline__ v2f cmul_plain(v2f a, v2f b)
 {
@@ -289,35 +438,57 @@ __device__ __forceinline__ v2f cmul_plain(v2f a, v2f b)
   return r;
 }
 
-// half of srslte_pss_cfo_compute: sum_{m in [m_begin, m_begin+64)} h[m] * r[m]   
-template <typename LoadFn>
-__device__ __forceinline__ v2f cfo_half_dot(const v2f *__restrict__ h, int m_begin, LoadFn ld)
+// (p0+p1)+(p2+p3) of four consecutive lanes starting at `base`
+__device__ __forceinline__ float sum4_lanes(float v, int base)
 {
-  v2f y = {0.f, 0.f};
-#pragma unroll 1
-  for (int m = m_begin; m < m_begin + 64; ++m) {
-    const v2f p = cmul_plain(h[m], ld(m));
-    y.x = __fadd_rn(y.x, p.x);
-    y.y = __fadd_rn(y.y, p.y);
-  }
-  return y;
+  return __fadd_rn(__fadd_rn(rlane(v, base), rlane(v, base + 1)), __fadd_rn(rlane(v, base + 2), rlane(v, base + 3)));
 }
 
-__device__ __forceinline__ float cfo_from_halves(v2f y0, v2f y1)
+// srslte_pss_cfo_compute: y_half = sum_{m in half} h[m] r[m] as four interleaved
+// partial sums (m mod 4); cfo = arg(conj(y0) y1) / pi.  h, r: 128 entries each (LDS or global).
+__device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 {
-  v2f c = {y0.x, -y0.y};
+  const int lane = threadIdx.x & 63;
+  v2f y = {0.f, 0.f};
+  if (lane < 8) {
+    const int half = lane >> 2, l = lane & 3;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int m = 64 * half + 4 * j + l;
+      const v2f p = cmul_plain(h[m], r[m]);
+      y.x = __fadd_rn(y.x, p.x);
+      y.y = __fadd_rn(y.y, p.y);
+    }
+  }
+  const v2f y0 = {sum4_lanes(y.x, 0), sum4_lanes(y.y, 0)};
+  const v2f y1 = {sum4_lanes(y.x, 4), sum4_lanes(y.y, 4)};
+  const v2f c = {y0.x, -y0.y};
   const v2f z = cmul_plain(c, y1);
   return (float)(atan2((double)z.y, (double)z.x) / 3.14159265358979323846);
 }
 
-// compute_moving_avg, lib/pss_impl.cc:94-109 (double accumulator)
-__device__ __forceinline__ float moving_avg(const float *data, uint32_t npts)
+// compute_moving_avg (lib/pss_impl.cc:94-109): sequential double sum of the first min(npts, 200)
+// ring entries, the entry `new_idx` taken as `new_val` (it is being written by this call).
+// Lanes fetch four entries each; the sum then runs strictly in index order through v_readlane.
+__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val)
 {
   if (!npts) return 0.0f;
   if (npts > (uint32_t)kMovingAvgSz) npts = kMovingAvgSz;
+  const uint32_t lane = threadIdx.x & 63;
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = lane + 64 * k;
+    float f = (i < (uint32_t)kMovingAvgSz) ? ring[i] : 0.f;
+    if (i == new_idx) f = new_val;
+    v[k] = (i < npts) ? f : 0.f; // x + 0.0 leaves the running sum unchanged
+  }
   double acc = 0.0;
-#pragma unroll 1
-  for (uint32_t i = 0; i < npts; ++i) acc = __dadd_rn(acc, (double)data[i]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int l = 0; l < 64; ++l)
+      if (64 * k + l < kMovingAvgSz) acc = __dadd_rn(acc, (double)rlane(v[k], l));
   return (float)(acc / (double)npts);
 }
 
@@ -335,33 +506,37 @@ __device__ __forceinline__ v2f cfo_rotate(const cf32 *__restrict__ tab, float ph
   return r;
 }
 
-// one (hypothesis, symbol) term of srslte_sync_detect_cp: R = Re sum tail*conj(cp), C = L*avg_power(cp)
-__device__ __forceinline__ void cp_term(const v2f *p, int L, float *R, float *C)
+// srslte_sync_detect_cp for peak_pos >= 480 (three symbols per hypothesis).
+// in: samples such that in[peak_pos - 480 ...] is readable; `base` = index of sample (peak_pos-480).
+// Lane (hyp, sym, l) = lanes 0..23 sums every 4th term; returns LT_CP_NORM / LT_CP_EXT and updates
+// the two EMAs (wave-uniform).
+__device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_avg, float &m_ext_avg)
 {
-  float dre = 0.f, pw = 0.f;
-#pragma unroll 1
-  for (int i = 0; i < L; ++i) {
-    const v2f a = p[kSymbolSz + i], b = p[i];
-    dre = __fadd_rn(dre, __fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));
-    pw = __fadd_rn(pw, __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y)));
-  }
-  *R = dre;
-  *C = __fmul_rn((float)L, pw / (float)L);
-}
-
-// decision part of srslte_sync_detect_cp from the six terms; updates the two EMAs
-__device__ __forceinline__ int cp_decide(const float R3[2][3], const float C3[2][3], float &m_norm_avg,
-                                         float &m_ext_avg)
-{
-  float R[2], M[2];
-  for (int h = 0; h < 2; ++h) {
-    float r = 0.f, c = 0.f;
-    for (int s = 0; s < 3; ++s) {
-      r = __fadd_rn(r, R3[h][s]);
-      c = __fadd_rn(c, C3[h][s]);
+  const int lane = threadIdx.x & 63;
+  float pr = 0.f, pp = 0.f;
+  if (lane < 24) {
+    const int hs = lane >> 2, l = lane & 3, hyp = hs / 3, sym = hs % 3;
+    const int L = hyp ? 32 : 9;
+    const v2f *p = win480 + (480 - 3 * (kSymbolSz + L)) + sym * (kSymbolSz + L);
+    for (int i = l; i < L; i += 4) {
+      const v2f a = p[kSymbolSz + i], b = p[i];
+      pr = __fadd_rn(pr, __fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));
+      pp = __fadd_rn(pp, __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y)));
     }
-    R[h] = r;
-    M[h] = (c > 0.f) ? r / c : 0.f;
+  }
+  float R[2], M[2];
+#pragma unroll
+  for (int hyp = 0; hyp < 2; ++hyp) {
+    const float L = hyp ? 32.f : 9.f;
+    float r = 0.f, c = 0.f;
+#pragma unroll
+    for (int sym = 0; sym < 3; ++sym) {
+      const int base = 4 * (3 * hyp + sym);
+      r = __fadd_rn(r, sum4_lanes(pr, base));
+      c = __fadd_rn(c, __fmul_rn(L, sum4_lanes(pp, base) / L));
+    }
+    R[hyp] = r;
+    M[hyp] = (c > 0.f) ? r / c : 0.f;
   }
   const float alpha = 0.1f;
   m_norm_avg = __fadd_rn(__fmul_rn(alpha, M[0] / 3.0f), __fmul_rn(1.0f - alpha, m_norm_avg));
@@ -371,56 +546,69 @@ __device__ __forceinline__ int cp_decide(const float R3[2][3], const float C3[2]
   return (R[0] > R[1]) ? LT_CP_NORM : LT_CP_EXT;
 }
 
-// one of the 62 occupied bins of the 128-point DFT of the SSS symbol (double accumulation)
-__device__ __forceinline__ v2f sss_dft_bin(const v2f *sym, int k, const double *dcos, const double *dsin)
+// One eighth (n mod 8 == l) of one of the 62 occupied bins of the 128-point DFT of the SSS symbol,
+// single precision; the eighths are combined pairwise by sss_dft_combine.
+__device__ __forceinline__ v2f sss_dft_partial(const v2f *sym, int k, int l, const float *twc, const float *tws)
 {
   const int bin = (k < 31) ? (k - 31) : (k - 30);
-  double sr = 0.0, si = 0.0;
-#pragma unroll 1
-  for (int n = 0; n < kSymbolSz; ++n) {
-    const int e = ((bin * n) % 128 + 128) % 128;
-    const double c = dcos[e], s = dsin[e];
-    const double re = (double)sym[n].x, im = (double)sym[n].y;
-    sr = __dadd_rn(sr, __dsub_rn(__dmul_rn(re, c), __dmul_rn(im, s)));
-    si = __dadd_rn(si, __dadd_rn(__dmul_rn(re, s), __dmul_rn(im, c)));
+  float sr = 0.f, si = 0.f;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int n = 8 * j + l;
+    const int e = (bin * n) & 127;
+    const float c = twc[e], s = tws[e];
+    const v2f x = sym[n];
+    sr = __fadd_rn(sr, __fsub_rn(__fmul_rn(x.x, c), __fmul_rn(x.y, s)));
+    si = __fadd_rn(si, __fadd_rn(__fmul_rn(x.x, s), __fmul_rn(x.y, c)));
   }
-  v2f r = {(float)sr, (float)si};
+  v2f r = {sr, si};
+  return r;
+}
+__device__ __forceinline__ v2f sss_dft_combine(const v2f *p)
+{
+  v2f r;
+  r.x = __fadd_rn(__fadd_rn(__fadd_rn(p[0].x, p[1].x), __fadd_rn(p[2].x, p[3].x)),
+                  __fadd_rn(__fadd_rn(p[4].x, p[5].x), __fadd_rn(p[6].x, p[7].x)));
+  r.y = __fadd_rn(__fadd_rn(__fadd_rn(p[0].y, p[1].y), __fadd_rn(p[2].y, p[3].y)),
+                  __fadd_rn(__fadd_rn(p[4].y, p[5].y), __fadd_rn(p[6].y, p[7].y)));
   return r;
 }
 
-// |sum_i Y[2i+odd] * c[i] * z[i] * s~[(i+m)%31]|^2 for shift m  (corr_all_sz_partial, M = 1)
-__device__ __forceinline__ float sss_corr(const v2f *Y, int odd, const float *__restrict__ c,
-                                          const float *__restrict__ z, int zshift,
-                                          const float *__restrict__ s, int m)
+// rotate a 31-bit mask: result bit i = mask bit (i + sh) % 31
+__device__ __forceinline__ uint32_t rot31(uint32_t mask, int sh)
 {
-  float re = 0.f, im = 0.f;
-#pragma unroll 1
+  return ((mask >> sh) | (mask << (31 - sh))) & 0x7fffffffu;
+}
+
+// |sum_i Y[2i+odd] c[i] z1[i] s~[(i+m)%31]|^2 for shift m (corr_all_sz_partial, M = 1), four
+// interleaved partial sums (i mod 4) per component.  The +-1 factors only flip signs, so they are
+// applied as one XOR of the sign bit: `signs` bit i = sign of c[i] z1[i] s~[(i+m)%31].
+__device__ __forceinline__ float sss_corr(const v2f *Y, int odd, uint32_t signs)
+{
+  float pr[4] = {0.f, 0.f, 0.f, 0.f}, pi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int i = 0; i < 31; ++i) {
     const v2f y = Y[2 * i + odd];
-    float yr = __fmul_rn(y.x, c[i]), yi = __fmul_rn(y.y, c[i]);
-    if (z) {
-      const float zz = z[(i + zshift) % 31];
-      yr = __fmul_rn(yr, zz);
-      yi = __fmul_rn(yi, zz);
-    }
-    const float sv = s[(i + m) % 31];
-    re = __fadd_rn(re, __fmul_rn(yr, sv));
-    im = __fadd_rn(im, __fmul_rn(yi, sv));
+    const uint32_t sg = (signs << (31 - i)) & 0x80000000u;
+    const float yr = __uint_as_float(__float_as_uint(y.x) ^ sg);
+    const float yi = __uint_as_float(__float_as_uint(y.y) ^ sg);
+    pr[i & 3] = __fadd_rn(pr[i & 3], yr);
+    pi[i & 3] = __fadd_rn(pi[i & 3], yi);
   }
+  const float re = __fadd_rn(__fadd_rn(pr[0], pr[1]), __fadd_rn(pr[2], pr[3]));
+  const float im = __fadd_rn(__fadd_rn(pi[0], pi[1]), __fadd_rn(pi[2], pi[3]));
   return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
 }
 
-__device__ __forceinline__ int first_max31(const float *corr)
+// first maximum over lanes 0..30 of a wave (srslte_vec_max_fi): lane index and value, wave-uniform
+__device__ __forceinline__ int first_max31_wave(float corr, float *value)
 {
-  float m = -FLT_MAX;
-  int p = 0;
-#pragma unroll 1
-  for (int i = 0; i < 31; ++i)
-    if (corr[i] > m) {
-      m = corr[i];
-      p = i;
-    }
-  return p;
+  const int lane = threadIdx.x & 63;
+  const float v = (lane < 31) ? corr : -FLT_MAX;
+  const float mx = wave_max_f(v);
+  const int idx = wave_min_i((lane < 31 && v == mx) ? lane : INT_MAX);
+  *value = mx;
+  return (idx == INT_MAX) ? 0 : idx;
 }
 
 // srslte_sss_N_id_1 with its unsigned wrap
@@ -435,65 +623,69 @@ __device__ __forceinline__ int sss_n_id_1(const DeviceTables *__restrict__ tab, 
   return n;
 }
 
-// Per-workgroup LDS copy of the small tables the sequential (bit-exact) sums walk through, so
-// that their dependent loads are LDS reads rather than global-memory round trips.
+// Per-workgroup LDS copy of the small tables the tracked-emit path walks through.
 struct LdsTables {
-  double dcos[128], dsin[128];
+  float twc[128], tws[128]; // DFT-128 twiddles, single precision
   v2f taps[128];
-  float c0[32], c1[32], s[32], z[32];
+  uint32_t s_mask, z_mask, c0_mask, c1_mask; // m-sequence signs (bit i set <=> -1)
 };
 
 __device__ __forceinline__ void load_lds_tables(LdsTables &lt_, const DeviceTables *__restrict__ tab, int n_id_2)
 {
   for (int i = threadIdx.x; i < 128; i += blockDim.x) {
-    lt_.dcos[i] = tab->dft128_cos[i];
-    lt_.dsin[i] = tab->dft128_sin[i];
+    lt_.twc[i] = (float)tab->dft128_cos[i];
+    lt_.tws[i] = (float)tab->dft128_sin[i];
     v2f h = {tab->pss_taps[n_id_2][i].re, tab->pss_taps[n_id_2][i].im};
     lt_.taps[i] = h;
-    if (i < 32) {
-      lt_.c0[i] = tab->sss_c0[n_id_2][i];
-      lt_.c1[i] = tab->sss_c1[n_id_2][i];
-      lt_.s[i] = tab->sss_s[i];
-      lt_.z[i] = tab->sss_z[i];
-    }
+  }
+  if (threadIdx.x == 0) {
+    lt_.s_mask = tab->sss_s_mask;
+    lt_.z_mask = tab->sss_z_mask;
+    lt_.c0_mask = tab->sss_c0_mask[n_id_2];
+    lt_.c1_mask = tab->sss_c1_mask[n_id_2];
   }
 }
 
-// sss_impl::work body after the tag check (lib/sss_impl.cc:102-150) on S = half-frame samples
-// [480, 960) in LDS.  All threads of the block call it; results are uniform.
 struct SssResult {
   int cp, m0, m1, n_id_1;
   float m0_value, m1_value;
 };
 
+// srslte_sss_m0m1_partial after the DFT: every wave combines the partial bins into sc.Y (all waves
+// write identical values), then lanes 0..30 correlate against the 31 shifts.  Wave-uniform result.
+__device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_, SssResult &r)
+{
+  const int lane = threadIdx.x & 63;
+  if (lane < 62) sc.Y[lane] = sss_dft_combine(sc.Yp[lane]);
+  float corr = 0.f;
+  const uint32_t s_rot = (lane < 31) ? rot31(lt_.s_mask, lane) : 0u;
+  if (lane < 31) corr = sss_corr(sc.Y, 0, s_rot ^ lt_.c0_mask);
+  r.m0 = first_max31_wave(corr, &r.m0_value);
+  if (lane < 31) corr = sss_corr(sc.Y, 1, s_rot ^ lt_.c1_mask ^ rot31(lt_.z_mask, r.m0 % 8));
+  r.m1 = first_max31_wave(corr, &r.m1_value);
+}
+
+// sss_impl::work body after the tag check (lib/sss_impl.cc:102-150) on S = corrected half-frame
+// samples [480, 960) in LDS.  Block-wide (needs >= 496 threads for the DFT); one barrier inside.
+// The CP decision is cheap and made by every wave for itself; the m0/m1 search after the DFT runs
+// on wave 0 only -- its results are needed by nothing but the record thread 0 writes, so the
+// other waves move on (the returned m0/m1/n_id_1 are valid in wave 0 only).
 __device__ __forceinline__ SssResult sss_stage(const v2f *S, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
                                               float &m_norm_avg, float &m_ext_avg, Scratch &sc)
 {
   const int tid = threadIdx.x;
-  if (tid < 6) { // 2 hypotheses x 3 symbols, each summed sequentially by one lane
-    const int hyp = tid / 3, sym = tid % 3;
-    const int L = hyp ? 32 : 9;
-    const int p = kSlotLen - 3 * (kSymbolSz + L) + sym * (kSymbolSz + L) - kSssBase;
-    cp_term(S + p, L, &sc.cpR[hyp][sym], &sc.cpC[hyp][sym]);
-  }
-  __syncthreads();
   SssResult r;
-  r.cp = cp_decide(sc.cpR, sc.cpC, m_norm_avg, m_ext_avg);
-  const int cp_len = (r.cp == LT_CP_NORM) ? 9 : 32;               // srslte_sync_set_cp
+  r.m0 = r.m1 = r.n_id_1 = -1;
+  r.m0_value = r.m1_value = 0.f;
+  r.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg);
+  const int cp_len = (r.cp == LT_CP_NORM) ? 9 : 32;                 // srslte_sync_set_cp
   const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len - kSssBase; // lib/sss_impl.cc:110
-  if (tid < 62) sc.Y[tid] = sss_dft_bin(S + sss_idx, tid, lt_.dcos, lt_.dsin);
+  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S + sss_idx, tid >> 3, tid & 7, lt_.twc, lt_.tws);
   __syncthreads();
-  if (tid < 31) sc.corr[tid] = sss_corr(sc.Y, 0, lt_.c0, nullptr, 0, lt_.s, tid);
-  __syncthreads();
-  r.m0 = first_max31(sc.corr);
-  r.m0_value = sc.corr[r.m0];
-  __syncthreads();
-  if (tid < 31)
-    sc.corr[tid] = sss_corr(sc.Y, 1, lt_.c1, lt_.z, r.m0 % 8, lt_.s, tid);
-  __syncthreads();
-  r.m1 = first_max31(sc.corr);
-  r.m1_value = sc.corr[r.m1];
-  r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
+  if (tid < 64) {
+    sss_m0m1_wave(sc, lt_, r);
+    r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
+  }
   return r;
 }
 

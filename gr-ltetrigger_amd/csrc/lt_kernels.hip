@@ -29,6 +29,7 @@ struct ChainArgs {
   int track_after;
   int track_every;
   int ablate;             // diagnostics only (tools/probe.py): 1 = skip the window load
+  unsigned long long *prof; // diagnostics only: per-phase shader-clock sums of chain 0 (ablate & 8)
 };
 
 __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
   __shared__ v2f S[kSssLen];
   __shared__ v2f RAW[kSssLen];
   __shared__ LdsTables ltab;
+  __shared__ v2f TW[16 * 64];
+  __shared__ v2f SPEC[16 * 64];
   __shared__ float psr_data[kMovingAvgSz];
   __shared__ float cfo_data[kMovingAvgSz];
   __shared__ Scratch sc;
@@ -63,13 +66,10 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
     psr_data[i] = st->psr_data[i];
     cfo_data[i] = st->cfo_data[i];
   }
-  for (int i = tid; i < kWPad; i += kThreads) {
-    v2f z = {0.f, 0.f};
-    W[i] = z;
-    W[kWPad + kHalfFrame + i] = z;
-  }
   if (tid < kAvgLen - kConvLen) AVG[kConvLen + tid] = 0.f;
   load_lds_tables(ltab, tab, n_id_2);
+  load_filter_lds(TW, SPEC, tab, n_id_2);
+  const FilterLds fl = {TW, SPEC};
   int64_t pos = 0; // every run starts at sample 0 of the capture handed to it
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
@@ -78,6 +78,13 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
   float psr = st->psr, psr_max = st->psr_max;
   float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
   int nrec = 0;
+  const int call_base = st->n_calls;
+  v2f pf[kT];          // next window, prefetched (19 * 512 = 9728 >= 9600 samples)
+  int64_t pf_pos = -1; // stream position the prefetch belongs to, -1 = none
+#pragma unroll
+  for (int i = 0; i < kT; ++i) pf[i] = v2f{0.f, 0.f};
+  unsigned long long prof[24] = {0};
+  unsigned long long *profp = ((a.ablate & 8) && a.prof) ? prof : nullptr;
   __syncthreads();
 
   while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
@@ -87,10 +94,37 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
     // ---- lib/pss_impl.cc:163-172
     if (!is_tracking || timer == 0) {
       timer = a.track_every;
-      if (!(a.ablate & 1))
-        for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+      unsigned long long t0_ = profp ? __builtin_amdgcn_s_memtime() : 0;
+      if (!(a.ablate & 1)) {
+        if (pf_pos == pos) { // prefetched under the previous search's tail
+#pragma unroll
+          for (int i = 0; i < kT; ++i) {
+            const int k = tid + i * kThreads;
+            if (k < kHalfFrame) W[kWPad + k] = pf[i];
+          }
+        } else {
+          for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+        }
+        // the zero pads around the window (the matched filter used W as scratch last time)
+        for (int i = tid; i < kWPad; i += kThreads) W[i] = v2f{0.f, 0.f};
+        for (int i = kWPad + kHalfFrame + tid; i < kWLen; i += kThreads) W[i] = v2f{0.f, 0.f};
+      }
       __syncthreads();
-      const SearchResult r = search_window(W, AVG, ema, taps, sc, a.ablate);
+      if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // window load
+      search_front(W, AVG, ema, taps, fl, sc, a.ablate, profp);
+      // W is free from here on: start fetching the window a miss leads to (pos + 9600); the loads
+      // fly under the tail reductions and the state machine, a realigning hit discards them.
+      pf_pos = -1;
+      if (!(a.ablate & 1) && pos + 2 * kHalfFrame <= n) {
+        pf_pos = pos + kHalfFrame;
+#pragma unroll
+        for (int i = 0; i < kT; ++i) {
+          const int k = tid + i * kThreads;
+          if (k < kHalfFrame) pf[i] = x[pf_pos + k];
+        }
+      }
+      const SearchResult r = search_tail(AVG, sc, a.ablate, profp);
+      if (profp) prof[7] += 1;
       peak_pos = r.peak_pos;
       psr = r.psr;
       peak_value = r.peak_value;
@@ -143,25 +177,34 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
                      : nullptr;
 
       if (is_tracking) {
+        unsigned long long tt_ = profp ? __builtin_amdgcn_s_memtime() : 0;
+#define LT_TSTAMP(i)                                             \
+  if (profp) {                                                   \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    prof[i] += t_ - tt_;                                         \
+    tt_ = t_;                                                    \
+  }
         // stage half-frame samples [480, 960) once (coalesced); everything below reads LDS
         if (tid < kSssLen) RAW[tid] = ld_iq(x, n, hf0 + kSssBase + tid);
         __syncthreads();
-        // srslte_pss_cfo_compute on the uncorrected PSS symbol, lib/pss_impl.cc:199-201
-        if (tid < 2) {
-          const v2f *sym = RAW + (kSlotLen - kSymbolSz - kSssBase);
-          sc.y[tid] = cfo_half_dot(ltab.taps, tid * 64, [&](int m) { return sym[m]; });
-        }
-        __syncthreads();
-        if (tid == 0) {
-          const float c = cfo_from_halves(sc.y[0], sc.y[1]);
-          cfo_data[cfo_i % kMovingAvgSz] = c;
-          sc.cfo = c;
-          sc.mean_cfo = moving_avg(cfo_data, cfo_i + 1);
+        LT_TSTAMP(8) // stage raw samples
+        // srslte_pss_cfo_compute on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring
+        // update and mean_cfo(): every wave computes them redundantly, wave 0 keeps the ring
+        if (tid < 64) { // wave 0 alone: the other waves wait at the barrier instead of competing for issue slots
+          const float c = cfo_estimate_wave(ltab.taps, RAW + (kSlotLen - kSymbolSz - kSssBase));
+          const uint32_t slot = cfo_i % kMovingAvgSz;
+          const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c);
+          if (tid == 0) {
+            cfo_data[slot] = c;
+            sc.cfo = c;
+            sc.mean_cfo = mc;
+          }
         }
         __syncthreads();
         cfo_i++;
         cfo = sc.cfo;
         mean_cfo = sc.mean_cfo;
+        LT_TSTAMP(10) // cfo estimate + ring mean
         // srslte_cfo_correct(out, out, -mean_cfo()/symbol_sz), lib/pss_impl.cc:204
         const float freq = -mean_cfo / (float)kSymbolSz;
         const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
@@ -170,15 +213,18 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
           for (int i = tid; i < kHalfFrame; i += kThreads)
             out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
         __syncthreads();
+        LT_TSTAMP(11) // rotation
         // srslte_pss_chest (lib/pss_impl.cc:206-209): its output is never consumed -- dropped.
 
         // ---- sss_impl::work, no tracking_lost tag on this half-frame (lib/sss_impl.cc:102-150)
         const SssResult s = sss_stage(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
+        LT_TSTAMP(12) // sss stage
+        if (profp) prof[13] += 1;
         flags |= LT_F_SSS_RAN;
         if (s.cp == LT_CP_EXT) flags |= LT_F_CP_EXT;
         m0 = s.m0; m1 = s.m1; m0_value = s.m0_value; m1_value = s.m1_value;
         n_id_1 = s.n_id_1;
-        if (n_id_1 >= 0) {
+        if (n_id_1 >= 0) { // (m0, m1, n_id_1 are valid in wave 0, whose thread 0 writes the record)
           cell_id = 3 * n_id_1 + n_id_2; // srslte_sync_get_cell_id
           flags |= LT_F_TAG_CELL;
         }
@@ -201,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
     if (tid == 0) {
       lt_record r;
       r.in_pos = pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
-      r.call_idx = st->n_calls + nrec; r.flags = flags; r.peak_pos = used_peak_pos; r.score = score;
+      r.call_idx = call_base + nrec; r.flags = flags; r.peak_pos = used_peak_pos; r.score = score;
       r.psr = psr; r.peak_value = peak_value; r.cfo = cfo; r.mean_cfo = mean_cfo;
       r.m_norm_avg = m_norm_avg; r.m_ext_avg = m_ext_avg; r.m0_value = m0_value;
       r.m1_value = m1_value; r.m0 = m0; r.m1 = m1; r.n_id_1 = n_id_1; r.cell_id = cell_id;
@@ -212,6 +258,8 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
     pos = next_pos;
   }
 
+  if (profp && tid == 0)
+    for (int i = 0; i < 24; ++i) a.prof[(size_t)chain * 24 + i] = prof[i];
   // ---- store state
   __syncthreads();
 #pragma unroll
@@ -247,21 +295,22 @@ __global__ __launch_bounds__(kThreads) void lt_find_kernel(const v2f *__restrict
 {
   __shared__ v2f W[kWLen];
   __shared__ float AVG[kAvgLen];
+  __shared__ v2f TW[16 * 64];
+  __shared__ v2f SPEC[16 * 64];
   __shared__ Scratch sc;
   const int tid = threadIdx.x;
   float ema[kT];
 #pragma unroll
   for (int t = 0; t < kT; ++t) ema[t] = avg[tid * kT + t];
-  for (int i = tid; i < kWPad; i += kThreads) {
-    v2f z = {0.f, 0.f};
-    W[i] = z;
-    W[kWPad + kHalfFrame + i] = z;
-  }
+  for (int i = tid; i < kWPad; i += kThreads) W[i] = v2f{0.f, 0.f};
+  for (int i = kWPad + kHalfFrame + tid; i < kWLen; i += kThreads) W[i] = v2f{0.f, 0.f};
   if (tid < kAvgLen - kConvLen) AVG[kConvLen + tid] = 0.f;
   for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = win[i];
+  load_filter_lds(TW, SPEC, tab, n_id_2);
+  const FilterLds fl = {TW, SPEC};
   __syncthreads();
   const v2f *taps = reinterpret_cast<const v2f *>(tab->pss_taps[n_id_2]);
-  const SearchResult r = search_window(W, AVG, ema, taps, sc, 0);
+  const SearchResult r = search_window(W, AVG, ema, taps, fl, sc, 0);
 #pragma unroll
   for (int t = 0; t < kT; ++t) avg[tid * kT + t] = ema[t];
   if (tid == 0) {
@@ -274,12 +323,9 @@ __global__ __launch_bounds__(kThreads) void lt_find_kernel(const v2f *__restrict
 __global__ void lt_cfo_compute_kernel(const v2f *__restrict__ sym, const DeviceTables *__restrict__ tab,
                                       int n_id_2, float *cfo)
 {
-  __shared__ v2f y[2];
-  const int tid = threadIdx.x;
   const v2f *taps = reinterpret_cast<const v2f *>(tab->pss_taps[n_id_2]);
-  if (tid < 2) y[tid] = cfo_half_dot(taps, tid * 64, [&](int m) { return sym[m]; });
-  __syncthreads();
-  if (tid == 0) *cfo = cfo_from_halves(y[0], y[1]);
+  const float c = cfo_estimate_wave(taps, sym); // one wave
+  if (threadIdx.x == 0) *cfo = c;
 }
 
 __global__ void lt_cfo_correct_kernel(const v2f *__restrict__ in, v2f *__restrict__ out, int n,
@@ -295,33 +341,18 @@ struct SyncState {
   float m_norm_avg, m_ext_avg;
 };
 
-// srslte_sync_detect_cp with peak_pos = 960 semantics generalised: in = first peak_pos samples.
+// srslte_sync_detect_cp; in = first peak_pos samples, one wave.  The reference only ever passes
+// peak_pos = slot_length; three symbols per hypothesis are available for every peak_pos >= 480.
 __global__ void lt_detect_cp_kernel(const v2f *__restrict__ in, int peak_pos, SyncState *st, int *cp_out)
 {
-  __shared__ float R3[2][3], C3[2][3];
-  const int tid = threadIdx.x;
-  int nsym = peak_pos / (kSymbolSz + 32);
-  if (nsym > 3) nsym = 3;
-  if (nsym <= 0) {
-    if (tid == 0) *cp_out = LT_CP_NORM;
+  if (peak_pos < 480) { // fewer than three extended-CP symbols: outside what the path uses
+    if (threadIdx.x == 0) *cp_out = LT_CP_NORM;
     return;
   }
-  if (tid < 6) {
-    const int hyp = tid / 3, sym = tid % 3;
-    const int L = hyp ? 32 : 9;
-    if (sym < nsym) {
-      const int p = peak_pos - nsym * (kSymbolSz + L) + sym * (kSymbolSz + L);
-      cp_term(in + p, L, &R3[hyp][sym], &C3[hyp][sym]);
-    } else {
-      R3[hyp][sym] = 0.f;
-      C3[hyp][sym] = 0.f;
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float mn = st->m_norm_avg, me = st->m_ext_avg;
-    // nsym is 3 for every peak_pos >= 480, which is all the reference ever passes (slot_length)
-    *cp_out = cp_decide(R3, C3, mn, me);
+  float mn = st->m_norm_avg, me = st->m_ext_avg;
+  const int cp = cp_detect_wave(in + (peak_pos - 480), mn, me);
+  if (threadIdx.x == 0) {
+    *cp_out = cp;
     st->m_norm_avg = mn;
     st->m_ext_avg = me;
   }
@@ -332,24 +363,23 @@ struct M0M1Result {
   float m0_value, m1_value;
 };
 
-__global__ void lt_sss_m0m1_kernel(const v2f *__restrict__ sym, const DeviceTables *__restrict__ tab,
-                                   int n_id_2, M0M1Result *res)
+__global__ __launch_bounds__(512) void lt_sss_m0m1_kernel(const v2f *__restrict__ sym,
+                                                          const DeviceTables *__restrict__ tab, int n_id_2,
+                                                          M0M1Result *res)
 {
-  __shared__ v2f Y[62];
-  __shared__ float corr[32];
+  __shared__ Scratch sc;
+  __shared__ LdsTables ltab;
+  __shared__ v2f S[kSymbolSz];
   const int tid = threadIdx.x;
-  if (tid < 62) Y[tid] = sss_dft_bin(sym, tid, tab->dft128_cos, tab->dft128_sin);
+  load_lds_tables(ltab, tab, n_id_2);
+  if (tid < kSymbolSz) S[tid] = sym[tid];
   __syncthreads();
-  if (tid < 31) corr[tid] = sss_corr(Y, 0, tab->sss_c0[n_id_2], nullptr, 0, tab->sss_s, tid);
+  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S, tid >> 3, tid & 7, ltab.twc, ltab.tws);
   __syncthreads();
-  const int m0 = first_max31(corr);
-  const float v0 = corr[m0];
-  __syncthreads();
-  if (tid < 31) corr[tid] = sss_corr(Y, 1, tab->sss_c1[n_id_2], tab->sss_z, m0 % 8, tab->sss_s, tid);
-  __syncthreads();
+  SssResult r;
+  sss_m0m1_wave(sc, ltab, r);
   if (tid == 0) {
-    const int m1 = first_max31(corr);
-    res->m0 = m0; res->m1 = m1; res->m0_value = v0; res->m1_value = corr[m1];
+    res->m0 = r.m0; res->m1 = r.m1; res->m0_value = r.m0_value; res->m1_value = r.m1_value;
   }
 }
 
@@ -410,6 +440,7 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
   a.track_after = L.track_after;
   a.track_every = L.track_every;
   a.ablate = L.ablate;
+  a.prof = reinterpret_cast<unsigned long long *>(L.prof);
   hipLaunchKernelGGL(lt_chain_kernel, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
@@ -454,7 +485,7 @@ hipError_t launch_detect_cp(const void *in, int peak_pos, void *sync_state, int 
 hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2, void *res,
                            hipStream_t stream)
 {
-  hipLaunchKernelGGL(lt_sss_m0m1_kernel, dim3(1), dim3(64), 0, stream,
+  hipLaunchKernelGGL(lt_sss_m0m1_kernel, dim3(1), dim3(512), 0, stream,
                      reinterpret_cast<const v2f *>(sym), tab, n_id_2,
                      reinterpret_cast<M0M1Result *>(res));
   return hipGetLastError();

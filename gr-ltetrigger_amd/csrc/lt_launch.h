@@ -25,7 +25,8 @@ struct ChainLaunch {
   float psr_threshold;
   int track_after;
   int track_every;
-  int ablate = 0; // diagnostics only
+  int ablate = 0;       // diagnostics only
+  void *prof = nullptr; // diagnostics only: 8 x uint64 on the device
 };
 
 hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream);

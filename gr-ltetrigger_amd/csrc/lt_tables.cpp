@@ -2,6 +2,8 @@
 // rounded once to float).  See lt_tables.h for the sources.
 #include "lt_tables.h"
 
+#include "lt_fft.h"
+
 #include <cmath>
 #include <cstring>
 
@@ -93,6 +95,29 @@ void build_device_tables(DeviceTables *t)
     t->dft128_sin[e] = std::sin(ph);
   }
 
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int l = 0; l < 64; ++l) {
+      const double ph = -2.0 * kPi * (double)((l * k1) % 1024) / 1024.0;
+      t->fft_tw[k1 * 64 + l].re = (float)std::cos(ph);
+      t->fft_tw[k1 * 64 + l].im = (float)std::sin(ph);
+    }
+  for (int r = 0; r < 3; ++r) {
+    for (int l = 0; l < 64; ++l)
+      for (int reg = 0; reg < 16; ++reg) {
+        const int k = fft::out_index(l, reg);
+        double sr = 0.0, si = 0.0;
+        for (int m = 0; m < 128; ++m) {
+          const double ph = -2.0 * kPi * (double)((k * m) % 1024) / 1024.0;
+          const double c = std::cos(ph), sn = std::sin(ph);
+          const double hr = t->pss_taps[r][m].re, hi = t->pss_taps[r][m].im;
+          sr += hr * c - hi * sn;
+          si += hr * sn + hi * c;
+        }
+        t->pss_spec[r][reg * 64 + l].re = (float)(sr / 1024.0);
+        t->pss_spec[r][reg * 64 + l].im = (float)(si / 1024.0);
+      }
+  }
+
   float s[31], c[31], z[31];
   static const int ts[] = {2, 0}, tc[] = {3, 0}, tz[] = {4, 2, 1, 0};
   m_sequence(ts, 2, s);
@@ -101,9 +126,13 @@ void build_device_tables(DeviceTables *t)
   for (int i = 0; i < 31; ++i) {
     t->sss_s[i] = s[i];
     t->sss_z[i] = z[i];
+    if (s[i] < 0) t->sss_s_mask |= 1u << i;
+    if (z[i] < 0) t->sss_z_mask |= 1u << i;
     for (int r = 0; r < 3; ++r) {
       t->sss_c0[r][i] = c[(i + r) % 31];
       t->sss_c1[r][i] = c[(i + r + 3) % 31];
+      if (t->sss_c0[r][i] < 0) t->sss_c0_mask[r] |= 1u << i;
+      if (t->sss_c1[r][i] < 0) t->sss_c1_mask[r] |= 1u << i;
     }
   }
   // 36.211 Table 6.11.2.1-1 in closed form; T[m0][m1-1] = N_id_1, everything else stays 0

@@ -319,15 +319,21 @@ int orc_pss_find_pss(orc_pss_t *q, const orc_cf *in, float *psr)
 /* [srsLTE 18.06.1 srslte_pss_cfo_compute]; call site lib/pss_impl.cc:199-201. SURVEY A.3. */
 float orc_pss_cfo_compute(const orc_pss_t *q, const orc_cf *r)
 {
-  orc_cf y0 = cf(0, 0), y1 = cf(0, 0);
-  for (int m = 0; m < 64; m++) { /* srslte_vec_dot_prod_ccc: no conjugate */
-    orc_cf p = cmul(q->h[m], r[m]);
-    y0.re += p.re; y0.im += p.im;
+  /* srslte_vec_dot_prod_ccc (no conjugate) is a SIMD kernel in srsLTE: lane-wise partial sums
+   * followed by a horizontal add.  Restated with four interleaved partial sums per half
+   * (m mod 4), combined as (p0+p1)+(p2+p3); the kernels use the same order. */
+  orc_cf y[2];
+  for (int half = 0; half < 2; half++) {
+    orc_cf p[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int j = 0; j < 16; j++)
+      for (int l = 0; l < 4; l++) {
+        const int m = 64 * half + 4 * j + l;
+        orc_cf t = cmul(q->h[m], r[m]);
+        p[l].re += t.re; p[l].im += t.im;
+      }
+    y[half] = cf((p[0].re + p[1].re) + (p[2].re + p[3].re), (p[0].im + p[1].im) + (p[2].im + p[3].im));
   }
-  for (int m = 64; m < 128; m++) {
-    orc_cf p = cmul(q->h[m], r[m]);
-    y1.re += p.re; y1.im += p.im;
-  }
+  const orc_cf y0 = y[0], y1 = y[1];
   /* carg(conjf(y0)*y1)/M_PI: float product, double atan2 */
   orc_cf z = cmul(cf(y0.re, -y0.im), y1);
   return (float)(atan2((double)z.im, (double)z.re) / M_PI);
@@ -423,15 +429,16 @@ int orc_sync_detect_cp(orc_sync_t *q, const orc_cf *in, int peak_pos)
     const int L = cpl[hyp];
     const orc_cf *p = in + peak_pos - nsym * (fft + L);
     for (int s = 0; s < nsym; s++) {
-      float dre = 0.f, pw = 0.f;
-      float dim = 0.f;
-      for (int i = 0; i < L; i++) { /* dot_prod_conj_ccc(tail, cp): tail * conj(cp) */
+      /* srslte_vec_dot_prod_conj_ccc / srslte_vec_avg_power_cf are SIMD kernels: four interleaved
+       * partial sums (i mod 4) combined as (p0+p1)+(p2+p3); the kernels use the same order */
+      float pr[4] = {0, 0, 0, 0}, pp[4] = {0, 0, 0, 0};
+      for (int i = 0; i < L; i++) { /* dot_prod_conj_ccc(tail, cp): Re(tail * conj(cp)) */
         orc_cf a = p[fft + i], b = p[i];
-        dre += a.re * b.re + a.im * b.im;
-        dim += a.im * b.re - a.re * b.im;
-        pw += b.re * b.re + b.im * b.im;
+        pr[i & 3] += a.re * b.re + a.im * b.im;
+        pp[i & 3] += b.re * b.re + b.im * b.im;
       }
-      (void)dim;
+      const float dre = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      const float pw = (pp[0] + pp[1]) + (pp[2] + pp[3]);
       R[hyp] += dre;
       C[hyp] += (float)L * (pw / (float)L); /* cp_len * srslte_vec_avg_power_cf */
       p += fft + L;
@@ -450,29 +457,43 @@ int orc_sync_detect_cp(orc_sync_t *q, const orc_cf *in, int peak_pos)
 void orc_sss_m0m1(const orc_sync_t *q, const orc_cf *sym, int *m0, float *m0_value, int *m1,
                   float *m1_value)
 {
-  /* 128-point forward DFT, centred output with DC removed: 62 bins -31..-1,+1..+31 */
+  /* 128-point forward DFT (single precision like srsLTE's FFTW3F plan), centred output with DC
+   * removed: 62 bins -31..-1,+1..+31.  Each bin is eight interleaved partial sums (n mod 8)
+   * combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)); the kernels use the same order. */
+  static float twc[128], tws[128];
+  static int tw_ready;
+  if (!tw_ready) {
+    for (int e = 0; e < 128; e++) {
+      double ph = -2.0 * M_PI * (double)e / 128.0;
+      twc[e] = (float)cos(ph);
+      tws[e] = (float)sin(ph);
+    }
+    tw_ready = 1;
+  }
   orc_cf Y[62];
   for (int k = 0; k < 62; k++) {
     int bin = (k < 31) ? (k - 31) : (k - 30);
-    double sr = 0, si = 0;
+    float pr[8] = {0}, pi[8] = {0};
     for (int n = 0; n < 128; n++) {
-      int e = ((bin * n) % 128 + 128) % 128;
-      double ph = -2.0 * M_PI * (double)e / 128.0;
-      double c = cos(ph), s = sin(ph);
-      sr += (double)sym[n].re * c - (double)sym[n].im * s;
-      si += (double)sym[n].re * s + (double)sym[n].im * c;
+      const int e = (bin * n) & 127;
+      const float c = twc[e], sn = tws[e];
+      pr[n & 7] += sym[n].re * c - sym[n].im * sn;
+      pi[n & 7] += sym[n].re * sn + sym[n].im * c;
     }
-    Y[k] = cf((float)sr, (float)si);
+    Y[k] = cf(((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])),
+              ((pi[0] + pi[1]) + (pi[2] + pi[3])) + ((pi[4] + pi[5]) + (pi[6] + pi[7])));
   }
   orc_cf y0[31], y1[31];
   for (int i = 0; i < 31; i++) {
     y0[i] = cf(Y[2 * i].re * q->c0[i], Y[2 * i].im * q->c0[i]);
     y1[i] = cf(Y[2 * i + 1].re * q->c1[i], Y[2 * i + 1].im * q->c1[i]);
   }
+  /* corr_all_sz_partial (M = 1): srslte_vec_dot_prod_cfc is SIMD -> four interleaved partial sums */
   float corr[31];
   for (int m = 0; m < 31; m++) {
-    float re = 0, im = 0;
-    for (int i = 0; i < 31; i++) { re += y0[i].re * q->s[m][i]; im += y0[i].im * q->s[m][i]; }
+    float pr[4] = {0, 0, 0, 0}, pi[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 31; i++) { pr[i & 3] += y0[i].re * q->s[m][i]; pi[i & 3] += y0[i].im * q->s[m][i]; }
+    const float re = (pr[0] + pr[1]) + (pr[2] + pr[3]), im = (pi[0] + pi[1]) + (pi[2] + pi[3]);
     corr[m] = re * re + im * im;
   }
   *m0 = (int)vec_max_fi(corr, 31);
@@ -482,8 +503,9 @@ void orc_sss_m0m1(const orc_sync_t *q, const orc_cf *sym, int *m0, float *m0_val
     y1[i].im *= q->z1[*m0][i];
   }
   for (int m = 0; m < 31; m++) {
-    float re = 0, im = 0;
-    for (int i = 0; i < 31; i++) { re += y1[i].re * q->s[m][i]; im += y1[i].im * q->s[m][i]; }
+    float pr[4] = {0, 0, 0, 0}, pi[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 31; i++) { pr[i & 3] += y1[i].re * q->s[m][i]; pi[i & 3] += y1[i].im * q->s[m][i]; }
+    const float re = (pr[0] + pr[1]) + (pr[2] + pr[3]), im = (pi[0] + pi[1]) + (pi[2] + pi[3]);
     corr[m] = re * re + im * im;
   }
   *m1 = (int)vec_max_fi(corr, 31);

@@ -50,6 +50,22 @@ def main():
     nemit_tr = sum(int((((r["flags"] & lt.F_SSS_RAN) != 0)).sum()) for r in recs)
     per_chain_search = max(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
     k = float(np.median(ms))
+    if args.ablate & 8:
+        import ctypes
+        nchains = args.channels * 3
+        prof = (ctypes.c_ulonglong * (nchains * 24))()
+        lt.lib().lt_debug_get_profile(b._h, prof)
+        p = np.array(prof[:], dtype=np.float64).reshape(nchains, 24)
+        names = ["conv", "ema+mirror", "barrier", "argmax", "walk", "side", "load"]
+        tnames = ["stage", "cfo", "mean", "rotate", "sss"]
+        busiest = int(np.argmax(p[:, :7].sum(1) + p[:, 8:13].sum(1)))
+        tracker = int(np.argmax(p[:, 13]))
+        for c in {busiest, tracker, 0}:
+            nw, ne = max(p[c, 7], 1), max(p[c, 13], 1)
+            print(f"chain {c}: total {(p[c, :7].sum() + p[c, 8:13].sum()) / 1e3:.0f} kcycles; per searched window ({int(p[c, 7])}): " +
+                  ", ".join(f"{n}={p[c, i] / nw:.0f}" for i, n in enumerate(names)) +
+                  f"; per tracked emit ({int(p[c, 13])}): " +
+                  ", ".join(f"{n}={p[c, 8 + i] / ne:.0f}" for i, n in enumerate(tnames)))
     print(f"ablate={args.ablate} mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
           f"searches total {nsearch} (max/chain {per_chain_search}), tracked emits {nemit_tr}; "
           f"{args.channels * n / k / 1e6:.1f} Gsamp/s; {k * 1e3 / max(per_chain_search, 1):.2f} us per window of the busiest chain")
