@@ -28,7 +28,7 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kT = 19;                              // lags per thread
 constexpr int kWPad = 128;                          // zero samples in front of the window in LDS
-constexpr int kWLen = 8 * fft::kScratch;             // 10240 samples = 81920 B: window + zero pads; 8 wave-private FFT scratch areas
+constexpr int kWLen = 10240;                        // 81920 B: window + zero pads; doubles as FFT scratch (9 x 8448 B)
 constexpr int kAvgLen = kConvLen + 4;               // EMA mirror in LDS, [9728] is the always-zero lag
 constexpr int kSssBase = 480;                       // first half-frame sample the sss stage touches
 constexpr int kSssLen = kSlotLen - kSssBase;        // 480 samples [480, 960)
@@ -36,7 +36,9 @@ constexpr int kBlkValid = fft::kN - (kSymbolSz - 1);  // 897 valid lags per 1024
 constexpr int kBlocks = (kConvLen + kBlkValid - 1) / kBlkValid; // 11
 static_assert(kThreads * kT == kConvLen, "lag tiling must cover the convolution exactly");
 static_assert(kWPad + (kBlocks - 1) * kBlkValid - (kSymbolSz - 1) + fft::kN <= kWLen, "window buffer too short");
-static_assert(kBlocks <= 2 * kWaves, "two overlap-save rounds must cover the window");
+constexpr int kScratchInW = kWLen / fft::kScratch;    // 9 transforms' scratch fit in the window buffer
+static_assert(kBlocks <= 2 * kWaves, "one half-wave per overlap-save block");
+static_assert((kBlocks - kScratchInW) * fft::kScratch * 2 <= kAvgLen, "remaining scratch must fit in the metric buffer");
 
 // Persistent state of one chain (pss_impl + sss_impl members, lib/pss_impl.h:41-81,
 // lib/sss_impl.h:42-44), kept in HBM between launches.
@@ -184,52 +186,56 @@ __device__ __forceinline__ float wave_max_f(float f)
 // `ema` is this thread's slice of conv_output_avg.  Contains __syncthreads().
 // Overlap-save matched filter: |conv[lag]|^2 for all 9728 lags of the window in W, written to
 // `metric` (LDS).  Block b (1024 samples starting 127 before lag 897 b) is transformed by one
-// wave: FFT-1024, multiply by the filter spectrum, inverse FFT (as conj(FFT(conj(.)))), keep the
-// 897 alias-free outputs.  Waves 0..2 take a second block (11 blocks, 8 waves).  The window
-// buffer doubles as the FFT scratch once every wave holds its inputs in registers, so the call
-// contains two __syncthreads(); W is garbage afterwards, `metric` complete.
-__device__ __forceinline__ void ols_block(int lane, int b, fft::c32 v[16], const fft::c32 *tw, const fft::c32 *spec,
-                                          fft::c32 *scr, float *metric)
+// half-wave (csrc/lt_fft.h): FFT-1024, multiply by the filter spectrum, inverse FFT, keep the
+// 897 alias-free outputs; 11 blocks = 11 of the 16 half-waves, one
+// round.  Once every half-wave holds its 1024 inputs in registers, the window buffer (and, for the
+// last two blocks, the still unused metric buffer) serves as the FFT exchange scratch.  Three
+// __syncthreads() inside; W is garbage afterwards, `metric` complete.
+__device__ __forceinline__ void conv_metric_fft(v2f *W, float *metric, const v2f *tw, const v2f *spec,
+                                                unsigned long long *prof = nullptr)
 {
-  fft::phase_a(lane, v, tw, scr);
-  fft::phase_b(lane, v, tw, scr, scr);
-  fft::phase_c(lane, v, scr);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = fft::conj(fft::cmul(v[r], spec[r * 64 + lane]));
-  fft::scatter_natural(lane, v, scr);
-  fft::gather_strided(lane, v, scr);
-  fft::phase_a(lane, v, tw, scr);
-  fft::phase_b(lane, v, tw, scr, scr);
-  fft::phase_c(lane, v, scr);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = fft::out_index(lane, r);
-    const int lag = b * kBlkValid + i - (kSymbolSz - 1);
-    if (i >= kSymbolSz - 1 && lag < kConvLen)
-      metric[lag] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+  unsigned long long tq_ = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define LT_FSTAMP(i)                                             \
+  if (prof) {                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    prof[i] += t_ - tq_;                                         \
+    tq_ = t_;                                                    \
   }
-}
-
-__device__ __forceinline__ void conv_metric_fft(v2f *W, float *metric, const v2f *tw, const v2f *spec)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  fft::c32 xa[16], xb[16];
-  const int b0 = wave, b1 = wave + kWaves;
-  {
-    const v2f *p = W + kWPad + b0 * kBlkValid - (kSymbolSz - 1) + lane;
+  const int l = threadIdx.x & 31, b = threadIdx.x >> 5; // lane within the half-wave, block index
+  const bool active = b < kBlocks;
+  fft::c32 v[32];
+  if (active) {
+    const v2f *p = W + kWPad + b * kBlkValid - (kSymbolSz - 1) + l;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) xa[n1] = p[64 * n1];
+    for (int r = 0; r < 32; ++r) v[r] = p[32 * r];
   }
-  if (b1 < kBlocks) {
-    const v2f *p = W + kWPad + b1 * kBlkValid - (kSymbolSz - 1) + lane;
+  __syncthreads(); // every half-wave holds its inputs: W may now be overwritten
+  LT_FSTAMP(14)
+  if (active) {
+    fft::c32 *e = (b < kScratchInW) ? W + b * fft::kScratch
+                                    : reinterpret_cast<fft::c32 *>(metric) + (b - kScratchInW) * fft::kScratch;
+    fft::fft1024_stage1<false>(l, v, tw, e);
+    fft::fft1024_stage2<false>(l, v, e);
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) xb[n1] = p[64 * n1];
+    for (int r = 0; r < 32; ++r) v[r] = fft::cmul<false>(v[r], spec[r * 32 + l]);
+    fft::fft1024_stage1<true>(l, v, tw, e);
+    fft::fft1024_stage2<true>(l, v, e);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r].x = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
   }
-  __syncthreads(); // every wave holds its inputs: W may now be overwritten
-  fft::c32 *scr = W + wave * fft::kScratch;
-  ols_block(lane, b0, xa, tw, spec, scr, metric);
-  if (b1 < kBlocks) ols_block(lane, b1, xb, tw, spec, scr, metric);
+  LT_FSTAMP(15)
+  __syncthreads(); // no scratch in use any more: the metric buffer may be written
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const int i = l + 32 * r;
+      const int lag = b * kBlkValid + i - (kSymbolSz - 1);
+      if (i >= kSymbolSz - 1 && lag < kConvLen) metric[lag] = v[r].x;
+    }
+  }
   __syncthreads(); // metric[] complete
+  LT_FSTAMP(16)
+#undef LT_FSTAMP
 }
 
 #define LT_STAMP(i)                                              \
@@ -241,8 +247,8 @@ __device__ __forceinline__ void conv_metric_fft(v2f *W, float *metric, const v2f
 // Part 1 (search_front): matched filter, EMA, LDS mirror, ends with the block-wide barrier; after it
 // the window buffer W is no longer read.  Part 2 (search_tail): arg-max, walk, side lobes, PSR.
 struct FilterLds {
-  const v2f *tw;   // FFT twiddles [16][64] in LDS
-  const v2f *spec; // filter spectrum in wave-FFT register layout [16][64] in LDS
+  const v2f *tw;   // FFT twiddles W1024^(reg*lane), [32][32], in LDS
+  const v2f *spec; // filter spectrum / 1024, natural order, in LDS
 };
 
 __device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
@@ -264,7 +270,7 @@ __device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
 #pragma unroll
     for (int t = 0; t < kT; ++t) met[t] = __fadd_rn(__fmul_rn(acc[t].x, acc[t].x), __fmul_rn(acc[t].y, acc[t].y));
   } else {
-    conv_metric_fft(W, AVG, fl.tw, fl.spec); // AVG doubles as the staging area of the metric
+    conv_metric_fft(W, AVG, fl.tw, fl.spec, prof); // AVG doubles as the staging area of the metric
 #pragma unroll
     for (int t = 0; t < kT; ++t) met[t] = AVG[n0 + t];
   }
@@ -413,7 +419,7 @@ __device__ __forceinline__ SearchResult search_window(v2f *W, float *AVG, float 
 // copy the FFT twiddles and the filter spectrum of one root into LDS (2 x 8 KB)
 __device__ __forceinline__ void load_filter_lds(v2f *tw, v2f *spec, const DeviceTables *__restrict__ tab, int n_id_2)
 {
-  for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) {
+  for (int i = threadIdx.x; i < fft::kN; i += blockDim.x) {
     tw[i] = v2f{tab->fft_tw[i].re, tab->fft_tw[i].im};
     spec[i] = v2f{tab->pss_spec[n_id_2][i].re, tab->pss_spec[n_id_2][i].im};
   }

@@ -1,15 +1,17 @@
-// Wavefront-level 1024-point complex FFT used by the overlap-save matched filter.
+// Half-wave 1024-point complex FFT used by the overlap-save matched filter.
 //
-// One wave64 transforms one 1024-sample block; lane l owns 16 values at every stage and the three
-// stages (1024 = 16 x 16 x 4) exchange data through a wave-private LDS scratch area:
+// 32 lanes transform one 1024-sample block, 32 values per lane (1024 = 32 x 32), so a wave64 carries
+// two independent transforms and one transform needs a single trip through LDS:
 //
-//   phase A  lane l = m:          x[64 n1 + m], n1 = 0..15  --radix-16-->  A[k1] * W1024^(m k1)
-//   phase B  lane l = 16 m2 + k1: A[k1][4 m1 + m2], m1 = 0..15 --radix-16--> B[q1] * W64^(m2 q1)
-//   phase C  lane l = 16 g + k1:  B[k1][q1][m2], q1 = 4g + j   --radix-4-->  X[k1 + 16 q1 + 256 q2]
+//   element index i = lane + 32 * reg                      (same layout on input and output)
+//   stage 1  radix-32 over reg:  A[k1] = sum_n1 x[32 n1 + m] W32^(n1 k1),   times W1024^(m k1)
+//   exchange                       E[k1][m]  ->  lane k1 reads E[k1][0..31]
+//   stage 2  radix-32 over reg:  X[k1 + 32 q] = sum_m E[k1][m] W32^(m q)    (lane k1, reg q)
 //
-// so after phase C lane l holds X[k] for k = (l & 15) + 16 (4 (l >> 4) + j) + 256 q2, j, q2 = 0..3,
-// in register 4 j + q2.  The code is plain C++ over a 2-float vector type and an explicit "LDS"
-// pointer so that tests/fft_host_check.cpp can run it lane by lane on the CPU.
+// Because output element k again sits at lane k % 32, register k / 32, the inverse transform
+// (same code, conjugated twiddles) can be applied to the product with the filter spectrum directly.
+// Plain C++ over a 2-float vector type and an explicit "LDS" pointer, so that
+// tests/hostcheck/fft_host_check.cpp can run it lane by lane on the CPU.
 #pragma once
 
 #if defined(__HIP__) // compiling in HIP mode (not merely "with hipcc")
@@ -24,104 +26,122 @@ namespace fft {
 typedef float c32 __attribute__((ext_vector_type(2)));
 
 constexpr int kN = 1024;
-constexpr int kRowA = 66;         // row stride of exchange 1 / 2 (64 + 2: conflict-free ds_read_b64)
-constexpr int kScratch = 1280;    // c32 entries of wave-private scratch (exchange 3 pads 16 per 64)
+constexpr int kRow = 33;             // row stride of the exchange (32 + 1: conflict-free both ways)
+constexpr int kScratch = 32 * kRow;  // c32 entries of scratch per transform (8448 B)
 
-LT_HD c32 cmul(c32 a, c32 b)
+// Complex products written so that every sign lives in a constant operand of a packed FMA (hipcc
+// turns a negated *variable* operand into v_xor + v_mov, but folds constants for free).
+// cmul<false>(a, b) = a * b,  cmul<true>(a, b) = a * conj(b).
+template <bool kConjB> LT_HD c32 cmul(c32 a, c32 b)
 {
-  c32 axx = {a.x, a.x}, ayy = {-a.y, a.y}, byx = {b.y, b.x};
-  return __builtin_elementwise_fma(ayy, byx, axx * b);
+  const c32 axx = {a.x, a.x}, ayy = {a.y, a.y}, byx = {b.y, b.x};
+  const c32 p = axx * b;   // (ax bx, ax by)
+  const c32 q = ayy * byx; // (ay by, ay bx)
+  if (kConjB) {
+    const c32 s = {1.f, -1.f};
+    return __builtin_elementwise_fma(p, s, q); // (ax bx + ay by, -ax by + ay bx)
+  }
+  const c32 s = {-1.f, 1.f};
+  return __builtin_elementwise_fma(q, s, p); // (ax bx - ay by, ax by + ay bx)
 }
-LT_HD c32 mul_mj(c32 a) { c32 r = {a.y, -a.x}; return r; } // a * (-j)
-LT_HD c32 conj(c32 a) { c32 r = {a.x, -a.y}; return r; }
+template <bool kInv> LT_HD c32 cw(c32 w) { return kInv ? c32{w.x, -w.y} : w; } // compile-time twiddle
 
-// forward radix-4 butterfly (W4 = -j): outputs y0..y3 for inputs a, b, c, d
-LT_HD void radix4(c32 a, c32 b, c32 c, c32 d, c32 &y0, c32 &y1, c32 &y2, c32 &y3)
+// radix-4 butterfly, forward (W4 = -j) or inverse (W4 = +j)
+template <bool kInv> LT_HD void radix4(c32 a, c32 b, c32 c, c32 d, c32 &y0, c32 &y1, c32 &y2, c32 &y3)
 {
-  const c32 s0 = a + c, s1 = a - c, s2 = b + d, s3 = mul_mj(b - d);
+  const c32 s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
+  const c32 tyx = {t.y, t.x};
+  const c32 mj = {1.f, -1.f}, pj = {-1.f, 1.f}; // t * (-j) = (t.y, -t.x);  t * (+j) = (-t.y, t.x)
   y0 = s0 + s2;
   y2 = s0 - s2;
-  y1 = s1 + s3;
-  y3 = s1 - s3;
+  y1 = __builtin_elementwise_fma(tyx, kInv ? pj : mj, s1);
+  y3 = __builtin_elementwise_fma(tyx, kInv ? mj : pj, s1);
 }
 
-// 16-point forward DFT in registers, natural order in and out (16 = 4 x 4, n = 4 n1 + n2,
-// k = k1 + 4 k2).
-LT_HD void fft16(c32 v[16])
+// 16-point DFT of v[0], v[S], ..., v[15 S] in place, natural order in and out
+// (16 = 4 x 4, n = 4 n1 + n2, k = k1 + 4 k2).
+template <int S, bool kInv> LT_HD void fft16(c32 *v)
 {
   c32 t[16]; // t[4 k1 + n2]
 #pragma unroll
-  for (int n2 = 0; n2 < 4; ++n2) radix4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2], t[n2], t[4 + n2], t[8 + n2], t[12 + n2]);
-  // twiddles W16^(n2 k1)
-  const c32 w1 = {0.92387953251128674f, -0.38268343236508977f};
-  const c32 w2 = {0.70710678118654752f, -0.70710678118654752f};
-  const c32 w3 = {0.38268343236508977f, -0.92387953251128674f};
-  const c32 w6 = {-0.70710678118654752f, -0.70710678118654752f};
-  const c32 w9 = {-0.92387953251128674f, 0.38268343236508977f};
-  t[4 * 1 + 1] = cmul(t[4 * 1 + 1], w1);
-  t[4 * 1 + 2] = cmul(t[4 * 1 + 2], w2);
-  t[4 * 1 + 3] = cmul(t[4 * 1 + 3], w3);
-  t[4 * 2 + 1] = cmul(t[4 * 2 + 1], w2);
-  t[4 * 2 + 2] = mul_mj(t[4 * 2 + 2]); // W16^4 = -j
-  t[4 * 2 + 3] = cmul(t[4 * 2 + 3], w6);
-  t[4 * 3 + 1] = cmul(t[4 * 3 + 1], w3);
-  t[4 * 3 + 2] = cmul(t[4 * 3 + 2], w6);
-  t[4 * 3 + 3] = cmul(t[4 * 3 + 3], w9);
+  for (int n2 = 0; n2 < 4; ++n2)
+    radix4<kInv>(v[S * n2], v[S * (4 + n2)], v[S * (8 + n2)], v[S * (12 + n2)], t[n2], t[4 + n2], t[8 + n2], t[12 + n2]);
+  const c32 w1 = cw<kInv>(c32{0.92387953251128674f, -0.38268343236508977f});
+  const c32 w2 = cw<kInv>(c32{0.70710678118654752f, -0.70710678118654752f});
+  const c32 w3 = cw<kInv>(c32{0.38268343236508977f, -0.92387953251128674f});
+  const c32 w4 = cw<kInv>(c32{0.f, -1.f});
+  const c32 w6 = cw<kInv>(c32{-0.70710678118654752f, -0.70710678118654752f});
+  const c32 w9 = cw<kInv>(c32{-0.92387953251128674f, 0.38268343236508977f});
+  t[4 * 1 + 1] = cmul<false>(t[4 * 1 + 1], w1);
+  t[4 * 1 + 2] = cmul<false>(t[4 * 1 + 2], w2);
+  t[4 * 1 + 3] = cmul<false>(t[4 * 1 + 3], w3);
+  t[4 * 2 + 1] = cmul<false>(t[4 * 2 + 1], w2);
+  t[4 * 2 + 2] = cmul<false>(t[4 * 2 + 2], w4);
+  t[4 * 2 + 3] = cmul<false>(t[4 * 2 + 3], w6);
+  t[4 * 3 + 1] = cmul<false>(t[4 * 3 + 1], w3);
+  t[4 * 3 + 2] = cmul<false>(t[4 * 3 + 2], w6);
+  t[4 * 3 + 3] = cmul<false>(t[4 * 3 + 3], w9);
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1)
-    radix4(t[4 * k1 + 0], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3], v[k1], v[k1 + 4], v[k1 + 8], v[k1 + 12]);
+    radix4<kInv>(t[4 * k1 + 0], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3], v[S * k1], v[S * (k1 + 4)],
+                 v[S * (k1 + 8)], v[S * (k1 + 12)]);
 }
 
-// Twiddle table tw[k1 * 64 + l] = W1024^(l k1), k1 = 0..15, l = 0..63 (c32, 8 KB).
-// index of the natural-order element held in register r = 4 j + q2 of lane l after phase C
-LT_HD int out_index(int l, int r) { return (l & 15) + 16 * (4 * (l >> 4) + (r >> 2)) + 256 * (r & 3); }
-// padded position of natural index k in exchange 3 (16 spare entries per 64: conflict-free both ways)
-LT_HD int pad3(int k) { return k + 16 * (k >> 6); }
-
-// ---- the phases.  Between two phases every lane's LDS writes must be visible to the whole wave.
-LT_HD void phase_a(int l, c32 v[16], const c32 *tw, c32 *lds)
+// 32-point DFT in registers, natural order in and out: two 16-point DFTs over the even and the odd
+// elements, W32^k on the odd half, radix-2 combine (X[k], X[k+16] = E[k] +- W32^k O[k]).
+template <bool kInv> LT_HD void fft32(c32 v[32])
 {
-  fft16(v);
+  fft16<2, kInv>(v);     // even elements: E[k] lands in v[2 k]
+  fft16<2, kInv>(v + 1); // odd elements:  O[k] lands in v[2 k + 1]
+  const c32 w[16] = {{1.f, 0.f},
+                     {0.98078528040323044f, -0.19509032201612826f},
+                     {0.92387953251128674f, -0.38268343236508977f},
+                     {0.83146961230254524f, -0.55557023301960222f},
+                     {0.70710678118654752f, -0.70710678118654752f},
+                     {0.55557023301960222f, -0.83146961230254524f},
+                     {0.38268343236508977f, -0.92387953251128674f},
+                     {0.19509032201612826f, -0.98078528040323044f},
+                     {0.f, -1.f},
+                     {-0.19509032201612826f, -0.98078528040323044f},
+                     {-0.38268343236508977f, -0.92387953251128674f},
+                     {-0.55557023301960222f, -0.83146961230254524f},
+                     {-0.70710678118654752f, -0.70710678118654752f},
+                     {-0.83146961230254524f, -0.55557023301960222f},
+                     {-0.92387953251128674f, -0.38268343236508977f},
+                     {-0.98078528040323044f, -0.19509032201612826f}};
+  c32 lo[16], hi[16];
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
-    if (k1) v[k1] = cmul(v[k1], tw[k1 * 64 + l]);
-    lds[k1 * kRowA + l] = v[k1];
+  for (int k = 0; k < 16; ++k) {
+    const c32 e = v[2 * k];
+    const c32 o = (k == 0) ? v[1] : cmul<false>(v[2 * k + 1], cw<kInv>(w[k]));
+    lo[k] = e + o;
+    hi[k] = e - o;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    v[k] = lo[k];
+    v[k + 16] = hi[k];
   }
 }
 
-LT_HD void phase_b(int l, c32 v[16], const c32 *tw, c32 *lds_in, c32 *lds_out)
+// tw[reg * 32 + lane] = W1024^(reg * lane), reg, lane = 0..31 (c32, 8 KB).
+// One 1024-point DFT (forward, or unnormalised inverse) by the 32 lanes of a half-wave; l = lane
+// within the half (0..31), v[reg] = element l + 32 reg on entry and on exit, e = this transform's
+// scratch (kScratch entries).  All 32 lanes must execute the two stages in lock step.
+template <bool kInv> LT_HD void fft1024_stage1(int l, c32 v[32], const c32 *tw, c32 *e)
 {
-  const int k1 = l & 15, m2 = l >> 4;
+  fft32<kInv>(v);
 #pragma unroll
-  for (int m1 = 0; m1 < 16; ++m1) v[m1] = lds_in[k1 * kRowA + 4 * m1 + m2];
-  fft16(v);
-#pragma unroll
-  for (int q1 = 0; q1 < 16; ++q1) {
-    if (q1) v[q1] = cmul(v[q1], tw[q1 * 64 + 16 * m2]); // W64^(m2 q1) = W1024^(16 m2 q1)
-    lds_out[k1 * kRowA + 4 * q1 + m2] = v[q1];
+  for (int k1 = 0; k1 < 32; ++k1) {
+    if (k1) v[k1] = cmul<kInv>(v[k1], tw[k1 * 32 + l]);
+    e[k1 * kRow + l] = v[k1];
   }
 }
-
-LT_HD void phase_c(int l, c32 v[16], const c32 *lds_in)
-{
-  const int k1 = l & 15, g = l >> 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const c32 *p = lds_in + k1 * kRowA + 4 * (4 * g + j);
-    radix4(p[0], p[1], p[2], p[3], v[4 * j + 0], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-  }
-}
-
-// natural-order registers (out_index layout) -> phase-A input layout (x[64 n1 + l]) via exchange 3
-LT_HD void scatter_natural(int l, const c32 v[16], c32 *lds)
+template <bool kInv> LT_HD void fft1024_stage2(int l, c32 v[32], const c32 *e)
 {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lds[pad3(out_index(l, r))] = v[r];
-}
-LT_HD void gather_strided(int l, c32 v[16], const c32 *lds)
-{
-#pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds[pad3(64 * n1 + l)];
+  for (int m = 0; m < 32; ++m) v[m] = e[l * kRow + m];
+  fft32<kInv>(v);
 }
 
 } // namespace fft

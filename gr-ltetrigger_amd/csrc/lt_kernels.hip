@@ -39,8 +39,8 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
   __shared__ v2f S[kSssLen];
   __shared__ v2f RAW[kSssLen];
   __shared__ LdsTables ltab;
-  __shared__ v2f TW[16 * 64];
-  __shared__ v2f SPEC[16 * 64];
+  __shared__ v2f TW[fft::kN];
+  __shared__ v2f SPEC[fft::kN];
   __shared__ float psr_data[kMovingAvgSz];
   __shared__ float cfo_data[kMovingAvgSz];
   __shared__ Scratch sc;
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kThreads) void lt_find_kernel(const v2f *__restrict
 {
   __shared__ v2f W[kWLen];
   __shared__ float AVG[kAvgLen];
-  __shared__ v2f TW[16 * 64];
-  __shared__ v2f SPEC[16 * 64];
+  __shared__ v2f TW[fft::kN];
+  __shared__ v2f SPEC[fft::kN];
   __shared__ Scratch sc;
   const int tid = threadIdx.x;
   float ema[kT];

@@ -2,8 +2,6 @@
 // rounded once to float).  See lt_tables.h for the sources.
 #include "lt_tables.h"
 
-#include "lt_fft.h"
-
 #include <cmath>
 #include <cstring>
 
@@ -95,28 +93,25 @@ void build_device_tables(DeviceTables *t)
     t->dft128_sin[e] = std::sin(ph);
   }
 
-  for (int k1 = 0; k1 < 16; ++k1)
-    for (int l = 0; l < 64; ++l) {
-      const double ph = -2.0 * kPi * (double)((l * k1) % 1024) / 1024.0;
-      t->fft_tw[k1 * 64 + l].re = (float)std::cos(ph);
-      t->fft_tw[k1 * 64 + l].im = (float)std::sin(ph);
+  for (int reg = 0; reg < 32; ++reg)
+    for (int l = 0; l < 32; ++l) {
+      const double ph = -2.0 * kPi * (double)((l * reg) % 1024) / 1024.0;
+      t->fft_tw[reg * 32 + l].re = (float)std::cos(ph);
+      t->fft_tw[reg * 32 + l].im = (float)std::sin(ph);
     }
-  for (int r = 0; r < 3; ++r) {
-    for (int l = 0; l < 64; ++l)
-      for (int reg = 0; reg < 16; ++reg) {
-        const int k = fft::out_index(l, reg);
-        double sr = 0.0, si = 0.0;
-        for (int m = 0; m < 128; ++m) {
-          const double ph = -2.0 * kPi * (double)((k * m) % 1024) / 1024.0;
-          const double c = std::cos(ph), sn = std::sin(ph);
-          const double hr = t->pss_taps[r][m].re, hi = t->pss_taps[r][m].im;
-          sr += hr * c - hi * sn;
-          si += hr * sn + hi * c;
-        }
-        t->pss_spec[r][reg * 64 + l].re = (float)(sr / 1024.0);
-        t->pss_spec[r][reg * 64 + l].im = (float)(si / 1024.0);
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 1024; ++k) {
+      double sr = 0.0, si = 0.0;
+      for (int m = 0; m < 128; ++m) {
+        const double ph = -2.0 * kPi * (double)((k * m) % 1024) / 1024.0;
+        const double c = std::cos(ph), sn = std::sin(ph);
+        const double hr = t->pss_taps[r][m].re, hi = t->pss_taps[r][m].im;
+        sr += hr * c - hi * sn;
+        si += hr * sn + hi * c;
       }
-  }
+      t->pss_spec[r][k].re = (float)(sr / 1024.0);
+      t->pss_spec[r][k].im = (float)(si / 1024.0);
+    }
 
   float s[31], c[31], z[31];
   static const int ts[] = {2, 0}, tc[] = {3, 0}, tz[] = {4, 2, 1, 0};

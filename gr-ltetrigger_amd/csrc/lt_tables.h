@@ -30,11 +30,11 @@ struct DeviceTables {
   int32_t nid1_table[30][30]; // T[m0][m1-1] = N_id_1, zero elsewhere
   // the same m-sequences as sign masks: bit i set <=> element i is -1
   uint32_t sss_s_mask, sss_z_mask, sss_c0_mask[3], sss_c1_mask[3];
-  // overlap-save matched filter (csrc/lt_fft.h): twiddles W1024^(l k1) as [k1][l], and the
-  // 1024-point spectrum of the zero-padded filter, divided by 1024, in the register layout the
-  // wave FFT leaves its output in: [n_id_2][r][l] = H[out_index(l, r)] / 1024
-  cf32 fft_tw[16 * 64];
-  cf32 pss_spec[3][16 * 64];
+  // overlap-save matched filter (csrc/lt_fft.h): twiddles W1024^(reg * lane) as [reg][lane], and
+  // the 1024-point spectrum of the zero-padded filter divided by 1024, natural order
+  // (element k = lane + 32 reg is what lane `lane` holds in register `reg`)
+  cf32 fft_tw[32 * 32];
+  cf32 pss_spec[3][1024];
 };
 
 void build_device_tables(DeviceTables *t);

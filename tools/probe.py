@@ -65,7 +65,9 @@ def main():
             print(f"chain {c}: total {(p[c, :7].sum() + p[c, 8:13].sum()) / 1e3:.0f} kcycles; per searched window ({int(p[c, 7])}): " +
                   ", ".join(f"{n}={p[c, i] / nw:.0f}" for i, n in enumerate(names)) +
                   f"; per tracked emit ({int(p[c, 13])}): " +
-                  ", ".join(f"{n}={p[c, 8 + i] / ne:.0f}" for i, n in enumerate(tnames)))
+                  ", ".join(f"{n}={p[c, 8 + i] / ne:.0f}" for i, n in enumerate(tnames)) +
+                  " | conv: " + ", ".join(f"{n}={p[c, 14 + i] / nw:.0f}" for i, n in
+                  enumerate(["inputs+barrier", "transforms", "metric+barriers"])))
     print(f"ablate={args.ablate} mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
           f"searches total {nsearch} (max/chain {per_chain_search}), tracked emits {nemit_tr}; "
           f"{args.channels * n / k / 1e6:.1f} Gsamp/s; {k * 1e3 / max(per_chain_search, 1):.2f} us per window of the busiest chain")
