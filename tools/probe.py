@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--mode", default="noise", choices=["noise", "clean", "mix"])
+    ap.add_argument("--mode", default="noise", choices=["noise", "clean", "mix", "decim"])
     ap.add_argument("--ablate", type=int, default=0, help="1 no window load, 2 no conv, 4 no reductions")
     args = ap.parse_args()
     import torch
@@ -23,6 +23,20 @@ def main():
     import bench
     dev = torch.device("cuda", 0)
     n = int(args.seconds * 1_920_000)
+    if args.mode == "decim":
+        # traffic calibration: the decimator reads n_in*8 B with 8 B/lane coalesced loads (the access
+        # shape of the chain kernel's window loads) and writes n_in*8/D B
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        x = torch.randn((args.channels, n, 2), generator=g, device=dev)
+        y = torch.empty((args.channels, n // 8, 2), device=dev)
+        d = lt.Decim(8)
+        s = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        for _ in range(args.reps):
+            d.run_device(x.data_ptr(), y.data_ptr(), args.channels, n, s.cuda_stream)
+        torch.cuda.synchronize()
+        print(f"mode=decim channels={args.channels} n={n}: reads {args.channels * n * 8} B, writes {args.channels * (n // 8) * 8} B per launch")
+        return
     frames = bench.base_frames(lt)
     if args.mode == "noise":
         g = torch.Generator(device=dev); g.manual_seed(1)
