@@ -70,6 +70,7 @@ struct Scratch {
   v2f Yp[62][8];   // SSS DFT partial sums [bin][n mod 8]
   v2f Y[62];
   float cfo, mean_cfo; // wave 0 -> everyone
+  double ring_sum;     // ds_add_f64 target of moving_avg_wave
 };
 
 struct SearchResult {
@@ -458,10 +459,15 @@ __device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
   v2f y = {0.f, 0.f};
   if (lane < 8) {
     const int half = lane >> 2, l = lane & 3;
-#pragma unroll 4
+    v2f hh[16], rr[16]; // all LDS reads first: one round trip instead of sixteen
+#pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int m = 64 * half + 4 * j + l;
-      const v2f p = cmul_plain(h[m], r[m]);
+      hh[j] = h[64 * half + 4 * j + l];
+      rr[j] = r[64 * half + 4 * j + l];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const v2f p = cmul_plain(hh[j], rr[j]);
       y.x = __fadd_rn(y.x, p.x);
       y.y = __fadd_rn(y.y, p.y);
     }
@@ -475,26 +481,69 @@ __device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 
 // compute_moving_avg (lib/pss_impl.cc:94-109): sequential double sum of the first min(npts, 200)
 // ring entries, the entry `new_idx` taken as `new_val` (it is being written by this call).
-// Lanes fetch four entries each; the sum then runs strictly in index order through v_readlane.
-__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val)
+// Lanes fetch four entries each.  Fast path: if the exponents of the non-zero entries lie within
+// 20 binades (and none is subnormal), every partial sum of any subset is a multiple of the smallest
+// ulp and below 2^53 of them, i.e. exactly representable in double -- the sequential sum rounds
+// nowhere, so it equals the exact sum, which is formed in 64-bit fixed point (ds_add_u64).
+// Otherwise the sum runs strictly in index order through v_readlane.
+// `scratch` = 8 bytes of LDS owned by the calling wave.
+__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val,
+                                                 double *scratch, unsigned long long *slow_count = nullptr)
 {
   if (!npts) return 0.0f;
   if (npts > (uint32_t)kMovingAvgSz) npts = kMovingAvgSz;
   const uint32_t lane = threadIdx.x & 63;
   float v[4];
+  uint32_t emax = 0, emin = 255, any_sub = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t i = lane + 64 * k;
     float f = (i < (uint32_t)kMovingAvgSz) ? ring[i] : 0.f;
     if (i == new_idx) f = new_val;
     v[k] = (i < npts) ? f : 0.f; // x + 0.0 leaves the running sum unchanged
+    const uint32_t bits = __float_as_uint(v[k]) & 0x7fffffffu;
+    const uint32_t e = bits >> 23;
+    if (bits != 0u) {
+      any_sub |= (e == 0u);
+      emax = e > emax ? e : emax;
+      emin = e < emin ? e : emin;
+    }
   }
-  double acc = 0.0;
+  // Exponent window [lo, lo+20] around the first lane's largest exponent; one ballot decides
+  // whether every non-zero entry of the wave lies inside it.
+  const uint32_t ref_max = __builtin_amdgcn_readfirstlane(emax);
+  const uint32_t lo = ref_max > 10u ? ref_max - 10u : 1u, hi = lo + 20u;
+  const bool outside = any_sub || (emax != 0u && (emax > hi || emax < lo)) || (emin != 255u && emin < lo);
+  const bool fast = (__ballot(outside) == 0ull) && hi < 255u;
+  double acc;
+  if (fast) {
+    // every value is an integer multiple of 2^(lo-150) below 2^45 of them: sum them as integers
+    long long part = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t bits = __float_as_uint(v[k]);
+      const uint32_t mag = bits & 0x7fffffffu;
+      if (mag != 0u) {
+        const long long m = (long long)((mag & 0x7fffffu) | 0x800000u) << ((mag >> 23) - lo);
+        part += (bits >> 31) ? -m : m;
+      }
+    }
+    unsigned long long *cell = reinterpret_cast<unsigned long long *>(scratch);
+    if (lane == 0) *cell = 0ull;
+    atomicAdd(cell, (unsigned long long)part); // ds_add_u64; two's complement wrap-around is fine
+    const long long total = (long long)*cell;
+    const long long tot_u = ((long long)__builtin_amdgcn_readfirstlane((int)(total >> 32)) << 32) |
+                            (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
+    acc = ldexp((double)tot_u, (int)lo - 150); // |total| < 2^53: exact
+  } else {
+    if (slow_count) *slow_count += 1;
+    acc = 0.0;
 #pragma unroll
-    for (int l = 0; l < 64; ++l)
-      if (64 * k + l < kMovingAvgSz) acc = __dadd_rn(acc, (double)rlane(v[k], l));
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int l = 0; l < 64; ++l)
+        if (64 * k + l < kMovingAvgSz) acc = __dadd_rn(acc, (double)rlane(v[k], l));
+  }
   return (float)(acc / (double)npts);
 }
 
@@ -524,11 +573,20 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
     const int hs = lane >> 2, l = lane & 3, hyp = hs / 3, sym = hs % 3;
     const int L = hyp ? 32 : 9;
     const v2f *p = win480 + (480 - 3 * (kSymbolSz + L)) + sym * (kSymbolSz + L);
-    for (int i = l; i < L; i += 4) {
-      const v2f a = p[kSymbolSz + i], b = p[i];
-      pr = __fadd_rn(pr, __fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));
-      pp = __fadd_rn(pp, __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y)));
+    v2f aa[8], bb[8]; // all LDS reads first
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = min(l + 4 * j, L - 1);
+      aa[j] = p[kSymbolSz + i];
+      bb[j] = p[i];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (l + 4 * j < L) {
+        const v2f a = aa[j], b = bb[j];
+        pr = __fadd_rn(pr, __fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)));
+        pp = __fadd_rn(pp, __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y)));
+      }
   }
   float R[2], M[2];
 #pragma unroll
@@ -553,19 +611,26 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
 }
 
 // One eighth (n mod 8 == l) of one of the 62 occupied bins of the 128-point DFT of the SSS symbol,
-// single precision; the eighths are combined pairwise by sss_dft_combine.
-__device__ __forceinline__ v2f sss_dft_partial(const v2f *sym, int k, int l, const float *twc, const float *tws)
+// single precision; the eighths are combined pairwise by sss_dft_combine.  tw[e] = (cos, sin) of
+// -2 pi e / 128.
+__device__ __forceinline__ v2f sss_dft_partial(const v2f *sym, int k, int l, const v2f *tw)
 {
   const int bin = (k < 31) ? (k - 31) : (k - 30);
   float sr = 0.f, si = 0.f;
-#pragma unroll 4
+  int e = (bin * l) & 127;
+  const int de = (bin * 8) & 127;
+  v2f ww[16], xx[16]; // all LDS reads first
+#pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int n = 8 * j + l;
-    const int e = (bin * n) & 127;
-    const float c = twc[e], s = tws[e];
-    const v2f x = sym[n];
-    sr = __fadd_rn(sr, __fsub_rn(__fmul_rn(x.x, c), __fmul_rn(x.y, s)));
-    si = __fadd_rn(si, __fadd_rn(__fmul_rn(x.x, s), __fmul_rn(x.y, c)));
+    ww[j] = tw[e];
+    xx[j] = sym[8 * j + l];
+    e = (e + de) & 127;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const v2f w = ww[j], x = xx[j];
+    sr = __fadd_rn(sr, __fsub_rn(__fmul_rn(x.x, w.x), __fmul_rn(x.y, w.y)));
+    si = __fadd_rn(si, __fadd_rn(__fmul_rn(x.x, w.y), __fmul_rn(x.y, w.x)));
   }
   v2f r = {sr, si};
   return r;
@@ -587,22 +652,40 @@ __device__ __forceinline__ uint32_t rot31(uint32_t mask, int sh)
 }
 
 // |sum_i Y[2i+odd] c[i] z1[i] s~[(i+m)%31]|^2 for shift m (corr_all_sz_partial, M = 1), four
-// interleaved partial sums (i mod 4) per component.  The +-1 factors only flip signs, so they are
-// applied as one XOR of the sign bit: `signs` bit i = sign of c[i] z1[i] s~[(i+m)%31].
-__device__ __forceinline__ float sss_corr(const v2f *Y, int odd, uint32_t signs)
+// interleaved partial sums (i mod 4) per component, combined as (p0+p1)+(p2+p3).  The +-1 factors
+// only flip signs, so they are applied as one XOR of the sign bit: `signs` bit i = sign of
+// c[i] z1[i] s~[(i+m)%31].  Lane m (half = 0) sums the terms with i mod 4 in {0,1}, lane m + 32
+// (half = 1) those with i mod 4 in {2,3}; the halves meet through one cross-lane exchange.
+// Returns the correlation in lanes 0..30 (garbage elsewhere).
+__device__ __forceinline__ float sss_corr(const v2f *Y, int odd, uint32_t signs, int half)
 {
-  float pr[4] = {0.f, 0.f, 0.f, 0.f}, pi[4] = {0.f, 0.f, 0.f, 0.f};
+  float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f; // partial sums p(2 half), p(2 half + 1)
+  v2f ya[8], yb[8]; // all LDS reads first (index 61 at most: Y has 62 entries)
 #pragma unroll
-  for (int i = 0; i < 31; ++i) {
-    const v2f y = Y[2 * i + odd];
-    const uint32_t sg = (signs << (31 - i)) & 0x80000000u;
-    const float yr = __uint_as_float(__float_as_uint(y.x) ^ sg);
-    const float yi = __uint_as_float(__float_as_uint(y.y) ^ sg);
-    pr[i & 3] = __fadd_rn(pr[i & 3], yr);
-    pi[i & 3] = __fadd_rn(pi[i & 3], yi);
+  for (int j = 0; j < 8; ++j) {
+    const int i0 = 4 * j + 2 * half, i1 = i0 + 1;
+    ya[j] = Y[min(2 * i0 + odd, 61)];
+    yb[j] = Y[min(2 * i1 + odd, 61)];
   }
-  const float re = __fadd_rn(__fadd_rn(pr[0], pr[1]), __fadd_rn(pr[2], pr[3]));
-  const float im = __fadd_rn(__fadd_rn(pi[0], pi[1]), __fadd_rn(pi[2], pi[3]));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i0 = 4 * j + 2 * half, i1 = i0 + 1;
+    if (i0 < 31) {
+      const v2f y = ya[j];
+      const uint32_t sg = ((signs >> i0) & 1u) << 31;
+      ar = __fadd_rn(ar, __uint_as_float(__float_as_uint(y.x) ^ sg));
+      ai = __fadd_rn(ai, __uint_as_float(__float_as_uint(y.y) ^ sg));
+    }
+    if (i1 < 31) {
+      const v2f y = yb[j];
+      const uint32_t sg = ((signs >> i1) & 1u) << 31;
+      br = __fadd_rn(br, __uint_as_float(__float_as_uint(y.x) ^ sg));
+      bi = __fadd_rn(bi, __uint_as_float(__float_as_uint(y.y) ^ sg));
+    }
+  }
+  const float sr = __fadd_rn(ar, br), si = __fadd_rn(ai, bi); // p0+p1 (half 0) or p2+p3 (half 1)
+  const float re = __fadd_rn(sr, __shfl_xor(sr, 32));          // lanes < 32: (p0+p1)+(p2+p3)
+  const float im = __fadd_rn(si, __shfl_xor(si, 32));
   return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
 }
 
@@ -612,9 +695,9 @@ __device__ __forceinline__ int first_max31_wave(float corr, float *value)
   const int lane = threadIdx.x & 63;
   const float v = (lane < 31) ? corr : -FLT_MAX;
   const float mx = wave_max_f(v);
-  const int idx = wave_min_i((lane < 31 && v == mx) ? lane : INT_MAX);
+  const unsigned long long hit = __ballot(lane < 31 && v == mx && v > -FLT_MAX);
   *value = mx;
-  return (idx == INT_MAX) ? 0 : idx;
+  return hit ? __builtin_ctzll(hit) : 0;
 }
 
 // srslte_sss_N_id_1 with its unsigned wrap
@@ -631,7 +714,7 @@ __device__ __forceinline__ int sss_n_id_1(const DeviceTables *__restrict__ tab, 
 
 // Per-workgroup LDS copy of the small tables the tracked-emit path walks through.
 struct LdsTables {
-  float twc[128], tws[128]; // DFT-128 twiddles, single precision
+  v2f tw128[128];           // DFT-128 twiddles (cos, sin)(-2 pi e / 128), single precision
   v2f taps[128];
   uint32_t s_mask, z_mask, c0_mask, c1_mask; // m-sequence signs (bit i set <=> -1)
 };
@@ -639,8 +722,7 @@ struct LdsTables {
 __device__ __forceinline__ void load_lds_tables(LdsTables &lt_, const DeviceTables *__restrict__ tab, int n_id_2)
 {
   for (int i = threadIdx.x; i < 128; i += blockDim.x) {
-    lt_.twc[i] = (float)tab->dft128_cos[i];
-    lt_.tws[i] = (float)tab->dft128_sin[i];
+    lt_.tw128[i] = v2f{(float)tab->dft128_cos[i], (float)tab->dft128_sin[i]};
     v2f h = {tab->pss_taps[n_id_2][i].re, tab->pss_taps[n_id_2][i].im};
     lt_.taps[i] = h;
   }
@@ -663,11 +745,11 @@ __device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_,
 {
   const int lane = threadIdx.x & 63;
   if (lane < 62) sc.Y[lane] = sss_dft_combine(sc.Yp[lane]);
-  float corr = 0.f;
-  const uint32_t s_rot = (lane < 31) ? rot31(lt_.s_mask, lane) : 0u;
-  if (lane < 31) corr = sss_corr(sc.Y, 0, s_rot ^ lt_.c0_mask);
+  const int m = lane & 31, half = lane >> 5;
+  const uint32_t s_rot = rot31(lt_.s_mask, m < 31 ? m : 0);
+  float corr = sss_corr(sc.Y, 0, s_rot ^ lt_.c0_mask, half);
   r.m0 = first_max31_wave(corr, &r.m0_value);
-  if (lane < 31) corr = sss_corr(sc.Y, 1, s_rot ^ lt_.c1_mask ^ rot31(lt_.z_mask, r.m0 % 8));
+  corr = sss_corr(sc.Y, 1, s_rot ^ lt_.c1_mask ^ rot31(lt_.z_mask, r.m0 % 8), half);
   r.m1 = first_max31_wave(corr, &r.m1_value);
 }
 
@@ -677,21 +759,33 @@ __device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_,
 // on wave 0 only -- its results are needed by nothing but the record thread 0 writes, so the
 // other waves move on (the returned m0/m1/n_id_1 are valid in wave 0 only).
 __device__ __forceinline__ SssResult sss_stage(const v2f *S, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
-                                              float &m_norm_avg, float &m_ext_avg, Scratch &sc)
+                                              float &m_norm_avg, float &m_ext_avg, Scratch &sc,
+                                              unsigned long long *prof = nullptr)
 {
   const int tid = threadIdx.x;
+  unsigned long long ts_ = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define LT_SSTAMP(i)                                             \
+  if (prof) {                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    prof[i] += t_ - ts_;                                         \
+    ts_ = t_;                                                    \
+  }
   SssResult r;
   r.m0 = r.m1 = r.n_id_1 = -1;
   r.m0_value = r.m1_value = 0.f;
   r.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg);
+  LT_SSTAMP(17)
   const int cp_len = (r.cp == LT_CP_NORM) ? 9 : 32;                 // srslte_sync_set_cp
   const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len - kSssBase; // lib/sss_impl.cc:110
-  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S + sss_idx, tid >> 3, tid & 7, lt_.twc, lt_.tws);
+  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S + sss_idx, tid >> 3, tid & 7, lt_.tw128);
+  LT_SSTAMP(18)
   __syncthreads();
+  LT_SSTAMP(19)
   if (tid < 64) {
     sss_m0m1_wave(sc, lt_, r);
     r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
   }
+  LT_SSTAMP(20)
   return r;
 }
 

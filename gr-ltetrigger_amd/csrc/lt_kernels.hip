@@ -32,8 +32,15 @@ struct ChainArgs {
   unsigned long long *prof; // diagnostics only: per-phase shader-clock sums of chain 0 (ablate & 8)
 };
 
-__global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
+// kDiag = true is the diagnostics build (tools/probe.py: ablation switches, in-kernel stamps, the
+// direct-form filter); the product launches kDiag = false, where all of that folds away.
+template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a_in)
 {
+  ChainArgs a = a_in;
+  if (!kDiag) {
+    a.ablate = 0;
+    a.prof = nullptr;
+  }
   __shared__ v2f W[kWLen];
   __shared__ float AVG[kAvgLen];
   __shared__ v2f S[kSssLen];
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
 #pragma unroll
   for (int i = 0; i < kT; ++i) pf[i] = v2f{0.f, 0.f};
   unsigned long long prof[24] = {0};
-  unsigned long long *profp = ((a.ablate & 8) && a.prof) ? prof : nullptr;
+  unsigned long long *profp = (kDiag && (a.ablate & 8) && a.prof) ? prof : nullptr;
   __syncthreads();
 
   while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
@@ -185,15 +192,19 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
     tt_ = t_;                                                    \
   }
         // stage half-frame samples [480, 960) once (coalesced); everything below reads LDS
-        if (tid < kSssLen) RAW[tid] = ld_iq(x, n, hf0 + kSssBase + tid);
+        // (by waves 1..7: wave 0 arrives last from the previous emission's m0/m1 search and finds
+        // the samples already in LDS)
+        for (int i = tid - 64; i >= 0 && i < kSssLen; i += kThreads - 64) RAW[i] = ld_iq(x, n, hf0 + kSssBase + i);
         __syncthreads();
         LT_TSTAMP(8) // stage raw samples
         // srslte_pss_cfo_compute on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring
         // update and mean_cfo(): every wave computes them redundantly, wave 0 keeps the ring
         if (tid < 64) { // wave 0 alone: the other waves wait at the barrier instead of competing for issue slots
           const float c = cfo_estimate_wave(ltab.taps, RAW + (kSlotLen - kSymbolSz - kSssBase));
+          LT_TSTAMP(9) // cfo estimate (wave 0)
           const uint32_t slot = cfo_i % kMovingAvgSz;
-          const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c);
+          const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c, &sc.ring_sum, profp ? &prof[22] : nullptr);
+          LT_TSTAMP(21) // ring mean (wave 0)
           if (tid == 0) {
             cfo_data[slot] = c;
             sc.cfo = c;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a)
         // srslte_pss_chest (lib/pss_impl.cc:206-209): its output is never consumed -- dropped.
 
         // ---- sss_impl::work, no tracking_lost tag on this half-frame (lib/sss_impl.cc:102-150)
-        const SssResult s = sss_stage(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
+        const SssResult s = sss_stage(S, ltab, tab, m_norm_avg, m_ext_avg, sc, profp);
         LT_TSTAMP(12) // sss stage
         if (profp) prof[13] += 1;
         flags |= LT_F_SSS_RAN;
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(512) void lt_sss_m0m1_kernel(const v2f *__restrict_
   load_lds_tables(ltab, tab, n_id_2);
   if (tid < kSymbolSz) S[tid] = sym[tid];
   __syncthreads();
-  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S, tid >> 3, tid & 7, ltab.twc, ltab.tws);
+  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S, tid >> 3, tid & 7, ltab.tw128);
   __syncthreads();
   SssResult r;
   sss_m0m1_wave(sc, ltab, r);
@@ -441,7 +452,10 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
   a.track_every = L.track_every;
   a.ablate = L.ablate;
   a.prof = reinterpret_cast<unsigned long long *>(L.prof);
-  hipLaunchKernelGGL(lt_chain_kernel, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  if (L.ablate)
+    hipLaunchKernelGGL(lt_chain_kernel<true>, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  else
+    hipLaunchKernelGGL(lt_chain_kernel<false>, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ def main():
                   ", ".join(f"{n}={p[c, i] / nw:.0f}" for i, n in enumerate(names)) +
                   f"; per tracked emit ({int(p[c, 13])}): " +
                   ", ".join(f"{n}={p[c, 8 + i] / ne:.0f}" for i, n in enumerate(tnames)) +
+                  f" | wave0: cfo={p[c, 9] / ne:.0f} ringmean={p[c, 21] / ne:.0f} (slow path {int(p[c, 22])}x) | sss: cp={p[c, 17] / ne:.0f} dft={p[c, 18] / ne:.0f} bar={p[c, 19] / ne:.0f} m0m1={p[c, 20] / ne:.0f}" +
                   " | conv: " + ", ".join(f"{n}={p[c, 14 + i] / nw:.0f}" for i, n in
                   enumerate(["inputs+barrier", "transforms", "metric+barriers"])))
     print(f"ablate={args.ablate} mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
