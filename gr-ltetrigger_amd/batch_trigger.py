@@ -32,13 +32,29 @@ class BatchTrigger:
         self.batch.reset()
         self.batch.run_host(iq)
         recs = self.batch.collect()
+        n = iq.shape[1]
+        return recs, self._events(recs, lambda ch, lo, hi: iq[ch, lo:hi], n)
+
+    def process_device(self, iq_tensor, stream=None):
+        """Same for a torch complex64 tensor [n_channels, n] already resident on the batch's device;
+        only the half-frames the MIB stage looks at are copied to the host."""
+        import torch
+        if iq_tensor.dtype != torch.complex64 or not iq_tensor.is_contiguous():
+            raise ValueError("need a contiguous complex64 tensor")
+        n = iq_tensor.shape[1]
+        self.batch.reset()
+        self.batch.run_device(torch.view_as_real(iq_tensor).data_ptr(), n, stream)
+        recs = self.batch.collect()
+        return recs, self._events(recs, lambda ch, lo, hi: iq_tensor[ch, lo:hi].cpu().numpy(), n)
+
+    def _events(self, recs, fetch, n):
         events = [[] for _ in range(self.n_channels)]
         for chain, r in enumerate(recs):
             ch = chain // 3
-            events[ch].extend(self._mib_stage(iq[ch], r))
-        return recs, events
+            events[ch].extend(self._mib_stage(lambda lo, hi, ch=ch: fetch(ch, lo, hi), n, r))
+        return events
 
-    def _mib_stage(self, x, recs):
+    def _mib_stage(self, fetch, n, recs):
         out = []
         published = None
         nof_ports_hint = 0
@@ -55,7 +71,7 @@ class BatchTrigger:
             hf = np.zeros(B.HALF_FRAME, np.complex64)
             p0 = int(r["out_pos"])
             lo = max(p0, 0)
-            hf[lo - p0:] = x[lo:p0 + B.HALF_FRAME]
+            hf[lo - p0:] = fetch(lo, p0 + B.HALF_FRAME)
             freq = float(np.float32(-r["mean_cfo"]) / np.float32(B.SYMBOL_SZ))
             hf = self.cfo.correct(hf, freq)
             cp_ext = bool(r["flags"] & B.F_CP_EXT)
