@@ -67,10 +67,8 @@ struct ChainState {
 struct Scratch {
   float tmax[kThreads]; // per-thread maximum of the EMA over its valid lags
   int tidx[kThreads];   // lag of that maximum
-  v2f Yp[62][8];   // SSS DFT partial sums [bin][n mod 8]
-  v2f Y[62];
+  v2f Y[62];           // occupied bins of the SSS symbol's FFT
   float cfo, mean_cfo; // wave 0 -> everyone
-  double ring_sum;     // ds_add_f64 target of moving_avg_wave
 };
 
 struct SearchResult {
@@ -185,6 +183,24 @@ __device__ __forceinline__ float wave_max_f(float f)
 // srslte_pss_find_pss on the window held in W (LDS, zero padded): lag metric, EMA(0.2),
 // arg-max, main-lobe walk, peak-to-side-lobe ratio (call site lib/pss_impl.cc:165).
 // `ema` is this thread's slice of conv_output_avg.  Contains __syncthreads().
+// value of lane (l ^ kMask): DPP quad permutes for 1 and 2, ds_swizzle (bit mode) up to 16,
+// ds_bpermute for 32
+template <int kMask> __device__ __forceinline__ int lane_xor_i(int v)
+{
+  if (kMask == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+  if (kMask == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+  if (kMask == 32) return __shfl_xor(v, 32);
+  return __builtin_amdgcn_ds_swizzle(v, (kMask << 10) | 0x1F); // and 0x1f, or 0, xor kMask
+}
+template <int kMask> __device__ __forceinline__ float lane_xor(float v)
+{
+  return __int_as_float(lane_xor_i<kMask>(__float_as_int(v)));
+}
+template <int kMask> __device__ __forceinline__ double lane_xor_d(double v)
+{
+  return __hiloint2double(lane_xor_i<kMask>(__double2hiint(v)), lane_xor_i<kMask>(__double2loint(v)));
+}
+
 // Overlap-save matched filter: |conv[lag]|^2 for all 9728 lags of the window in W, written to
 // `metric` (LDS).  Block b (1024 samples starting 127 before lag 897 b) is transformed by one
 // half-wave (csrc/lt_fft.h): FFT-1024, multiply by the filter spectrum, inverse FFT, keep the
@@ -451,29 +467,34 @@ __device__ __forceinline__ float sum4_lanes(float v, int base)
   return __fadd_rn(__fadd_rn(rlane(v, base), rlane(v, base + 1)), __fadd_rn(rlane(v, base + 2), rlane(v, base + 3)));
 }
 
-// srslte_pss_cfo_compute: y_half = sum_{m in half} h[m] r[m] as four interleaved
-// partial sums (m mod 4); cfo = arg(conj(y0) y1) / pi.  h, r: 128 entries each (LDS or global).
+// srslte_pss_cfo_compute: y_half = sum_{m in half} h[m] r[m] as eight interleaved
+// partial sums (m mod 8) combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) -- lanes 0..7 / 8..15 hold the
+// partial sums of the two halves and meet in an xor butterfly; cfo = arg(conj(y0) y1) / pi.
+// h, r: 128 entries each (LDS or global).
 __device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 {
   const int lane = threadIdx.x & 63;
   v2f y = {0.f, 0.f};
-  if (lane < 8) {
-    const int half = lane >> 2, l = lane & 3;
-    v2f hh[16], rr[16]; // all LDS reads first: one round trip instead of sixteen
+  if (lane < 16) {
+    const int base = 64 * (lane >> 3) + (lane & 7);
+    v2f hh[8], rr[8]; // all reads first: one round trip
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      hh[j] = h[64 * half + 4 * j + l];
-      rr[j] = r[64 * half + 4 * j + l];
+    for (int j = 0; j < 8; ++j) {
+      hh[j] = h[base + 8 * j];
+      rr[j] = r[base + 8 * j];
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 8; ++j) {
       const v2f p = cmul_plain(hh[j], rr[j]);
       y.x = __fadd_rn(y.x, p.x);
       y.y = __fadd_rn(y.y, p.y);
     }
   }
-  const v2f y0 = {sum4_lanes(y.x, 0), sum4_lanes(y.y, 0)};
-  const v2f y1 = {sum4_lanes(y.x, 4), sum4_lanes(y.y, 4)};
+  y.x = __fadd_rn(y.x, lane_xor<1>(y.x)); y.y = __fadd_rn(y.y, lane_xor<1>(y.y));
+  y.x = __fadd_rn(y.x, lane_xor<2>(y.x)); y.y = __fadd_rn(y.y, lane_xor<2>(y.y));
+  y.x = __fadd_rn(y.x, lane_xor<4>(y.x)); y.y = __fadd_rn(y.y, lane_xor<4>(y.y));
+  const v2f y0 = {rlane(y.x, 0), rlane(y.y, 0)};
+  const v2f y1 = {rlane(y.x, 8), rlane(y.y, 8)};
   const v2f c = {y0.x, -y0.y};
   const v2f z = cmul_plain(c, y1);
   return (float)(atan2((double)z.y, (double)z.x) / 3.14159265358979323846);
@@ -484,11 +505,10 @@ __device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 // Lanes fetch four entries each.  Fast path: if the exponents of the non-zero entries lie within
 // 20 binades (and none is subnormal), every partial sum of any subset is a multiple of the smallest
 // ulp and below 2^53 of them, i.e. exactly representable in double -- the sequential sum rounds
-// nowhere, so it equals the exact sum, which is formed in 64-bit fixed point (ds_add_u64).
+// nowhere, so any association gives the same bits and an xor butterfly over the wave is used.
 // Otherwise the sum runs strictly in index order through v_readlane.
-// `scratch` = 8 bytes of LDS owned by the calling wave.
 __device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val,
-                                                 double *scratch, unsigned long long *slow_count = nullptr)
+                                                 unsigned long long *slow_count = nullptr)
 {
   if (!npts) return 0.0f;
   if (npts > (uint32_t)kMovingAvgSz) npts = kMovingAvgSz;
@@ -517,24 +537,16 @@ __device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npt
   const bool fast = (__ballot(outside) == 0ull) && hi < 255u;
   double acc;
   if (fast) {
-    // every value is an integer multiple of 2^(lo-150) below 2^45 of them: sum them as integers
-    long long part = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t bits = __float_as_uint(v[k]);
-      const uint32_t mag = bits & 0x7fffffffu;
-      if (mag != 0u) {
-        const long long m = (long long)((mag & 0x7fffffu) | 0x800000u) << ((mag >> 23) - lo);
-        part += (bits >> 31) ? -m : m;
-      }
-    }
-    unsigned long long *cell = reinterpret_cast<unsigned long long *>(scratch);
-    if (lane == 0) *cell = 0ull;
-    atomicAdd(cell, (unsigned long long)part); // ds_add_u64; two's complement wrap-around is fine
-    const long long total = (long long)*cell;
-    const long long tot_u = ((long long)__builtin_amdgcn_readfirstlane((int)(total >> 32)) << 32) |
-                            (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
-    acc = ldexp((double)tot_u, (int)lo - 150); // |total| < 2^53: exact
+    // no partial sum of these values can round: any association gives the reference's bits
+    acc = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    acc += lane_xor_d<1>(acc);
+    acc += lane_xor_d<2>(acc);
+    acc += lane_xor_d<4>(acc);
+    acc += lane_xor_d<8>(acc);
+    acc += lane_xor_d<16>(acc);
+    acc += lane_xor_d<32>(acc);
+    acc = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(acc)),
+                           __builtin_amdgcn_readfirstlane(__double2loint(acc)));
   } else {
     if (slow_count) *slow_count += 1;
     acc = 0.0;
@@ -588,6 +600,9 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
         pp = __fadd_rn(pp, __fadd_rn(__fmul_rn(b.x, b.x), __fmul_rn(b.y, b.y)));
       }
   }
+  // (p0+p1)+(p2+p3) of each group of four lanes, left in every lane of the group
+  pr = __fadd_rn(pr, lane_xor<1>(pr)); pp = __fadd_rn(pp, lane_xor<1>(pp));
+  pr = __fadd_rn(pr, lane_xor<2>(pr)); pp = __fadd_rn(pp, lane_xor<2>(pp));
   float R[2], M[2];
 #pragma unroll
   for (int hyp = 0; hyp < 2; ++hyp) {
@@ -596,8 +611,8 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
 #pragma unroll
     for (int sym = 0; sym < 3; ++sym) {
       const int base = 4 * (3 * hyp + sym);
-      r = __fadd_rn(r, sum4_lanes(pr, base));
-      c = __fadd_rn(c, __fmul_rn(L, sum4_lanes(pp, base) / L));
+      r = __fadd_rn(r, rlane(pr, base));
+      c = __fadd_rn(c, __fmul_rn(L, rlane(pp, base) / L));
     }
     R[hyp] = r;
     M[hyp] = (c > 0.f) ? r / c : 0.f;
@@ -610,39 +625,60 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
   return (R[0] > R[1]) ? LT_CP_NORM : LT_CP_EXT;
 }
 
-// One eighth (n mod 8 == l) of one of the 62 occupied bins of the 128-point DFT of the SSS symbol,
-// single precision; the eighths are combined pairwise by sss_dft_combine.  tw[e] = (cos, sin) of
-// -2 pi e / 128.
-__device__ __forceinline__ v2f sss_dft_partial(const v2f *sym, int k, int l, const v2f *tw)
+// 128-point forward FFT of the SSS symbol on one wave: iterative radix-2 decimation in time with the
+// oracle's butterfly, t = w b = (b.re w.re - b.im w.im, b.re w.im + b.im w.re), a' = a + t, b' = a - t,
+// w = W128^(k 128/len) from a float table tw[64].  Lane l owns elements 2l and 2l+1 of the
+// bit-reversed working array; stage len = 2 is lane-local, the later stages pair lane l with
+// l ^ (len/4) through an xor exchange.  The 62 occupied bins (-31..-1, +1..+31) go to Y[0..61] in LDS.
+template <int kHalfLanes> // = len / 4: the lane distance of this stage
+__device__ __forceinline__ void fft128_stage(int lane, v2f &a0, v2f &a1, const v2f *tw)
 {
-  const int bin = (k < 31) ? (k - 31) : (k - 30);
-  float sr = 0.f, si = 0.f;
-  int e = (bin * l) & 127;
-  const int de = (bin * 8) & 127;
-  v2f ww[16], xx[16]; // all LDS reads first
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    ww[j] = tw[e];
-    xx[j] = sym[8 * j + l];
-    e = (e + de) & 127;
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const v2f w = ww[j], x = xx[j];
-    sr = __fadd_rn(sr, __fsub_rn(__fmul_rn(x.x, w.x), __fmul_rn(x.y, w.y)));
-    si = __fadd_rn(si, __fadd_rn(__fmul_rn(x.x, w.y), __fmul_rn(x.y, w.x)));
-  }
-  v2f r = {sr, si};
-  return r;
+  constexpr int half = 2 * kHalfLanes; // element distance
+  constexpr int step = 64 / half;      // twiddle stride
+  const v2f o0 = {lane_xor<kHalfLanes>(a0.x), lane_xor<kHalfLanes>(a0.y)};
+  const v2f o1 = {lane_xor<kHalfLanes>(a1.x), lane_xor<kHalfLanes>(a1.y)};
+  const bool top = (lane & kHalfLanes) == 0;
+  const int k0 = (2 * lane) & (half - 1);
+  const v2f w0 = tw[k0 * step], w1 = tw[(k0 + 1) * step];
+  const v2f u0 = top ? a0 : o0, v0 = top ? o0 : a0;
+  const v2f u1 = top ? a1 : o1, v1 = top ? o1 : a1;
+  const float t0r = __fsub_rn(__fmul_rn(v0.x, w0.x), __fmul_rn(v0.y, w0.y));
+  const float t0i = __fadd_rn(__fmul_rn(v0.x, w0.y), __fmul_rn(v0.y, w0.x));
+  const float t1r = __fsub_rn(__fmul_rn(v1.x, w1.x), __fmul_rn(v1.y, w1.y));
+  const float t1i = __fadd_rn(__fmul_rn(v1.x, w1.y), __fmul_rn(v1.y, w1.x));
+  a0.x = top ? __fadd_rn(u0.x, t0r) : __fsub_rn(u0.x, t0r);
+  a0.y = top ? __fadd_rn(u0.y, t0i) : __fsub_rn(u0.y, t0i);
+  a1.x = top ? __fadd_rn(u1.x, t1r) : __fsub_rn(u1.x, t1r);
+  a1.y = top ? __fadd_rn(u1.y, t1i) : __fsub_rn(u1.y, t1i);
 }
-__device__ __forceinline__ v2f sss_dft_combine(const v2f *p)
+
+__device__ __forceinline__ void sss_fft128_wave(const v2f *sym, const v2f *tw, v2f *Y)
 {
-  v2f r;
-  r.x = __fadd_rn(__fadd_rn(__fadd_rn(p[0].x, p[1].x), __fadd_rn(p[2].x, p[3].x)),
-                  __fadd_rn(__fadd_rn(p[4].x, p[5].x), __fadd_rn(p[6].x, p[7].x)));
-  r.y = __fadd_rn(__fadd_rn(__fadd_rn(p[0].y, p[1].y), __fadd_rn(p[2].y, p[3].y)),
-                  __fadd_rn(__fadd_rn(p[4].y, p[5].y), __fadd_rn(p[6].y, p[7].y)));
-  return r;
+  const int lane = threadIdx.x & 63;
+  const int br = (int)(__brev((unsigned)lane) >> 26); // 6-bit reversal: bitrev7(2l) = br, bitrev7(2l+1) = 64 + br
+  v2f a0 = sym[br], a1 = sym[64 + br];
+  { // len = 2: both points in this lane, w = W128^0
+    const v2f w = tw[0];
+    const float tr = __fsub_rn(__fmul_rn(a1.x, w.x), __fmul_rn(a1.y, w.y));
+    const float ti = __fadd_rn(__fmul_rn(a1.x, w.y), __fmul_rn(a1.y, w.x));
+    const v2f u = a0;
+    a0.x = __fadd_rn(u.x, tr); a0.y = __fadd_rn(u.y, ti);
+    a1.x = __fsub_rn(u.x, tr); a1.y = __fsub_rn(u.y, ti);
+  }
+  fft128_stage<1>(lane, a0, a1, tw);
+  fft128_stage<2>(lane, a0, a1, tw);
+  fft128_stage<4>(lane, a0, a1, tw);
+  fft128_stage<8>(lane, a0, a1, tw);
+  fft128_stage<16>(lane, a0, a1, tw);
+  fft128_stage<32>(lane, a0, a1, tw);
+  // lane l now holds X[2l], X[2l+1]
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int e = 2 * lane + c;
+    const v2f x = c ? a1 : a0;
+    if (e >= 1 && e <= 31) Y[e + 30] = x;
+    if (e >= 97) Y[e - 97] = x;
+  }
 }
 
 // rotate a 31-bit mask: result bit i = mask bit (i + sh) % 31
@@ -714,7 +750,7 @@ __device__ __forceinline__ int sss_n_id_1(const DeviceTables *__restrict__ tab, 
 
 // Per-workgroup LDS copy of the small tables the tracked-emit path walks through.
 struct LdsTables {
-  v2f tw128[128];           // DFT-128 twiddles (cos, sin)(-2 pi e / 128), single precision
+  v2f tw128[64];            // W128^e = (cos, sin)(-2 pi e / 128), e < 64, single precision
   v2f taps[128];
   uint32_t s_mask, z_mask, c0_mask, c1_mask; // m-sequence signs (bit i set <=> -1)
 };
@@ -722,7 +758,7 @@ struct LdsTables {
 __device__ __forceinline__ void load_lds_tables(LdsTables &lt_, const DeviceTables *__restrict__ tab, int n_id_2)
 {
   for (int i = threadIdx.x; i < 128; i += blockDim.x) {
-    lt_.tw128[i] = v2f{(float)tab->dft128_cos[i], (float)tab->dft128_sin[i]};
+    if (i < 64) lt_.tw128[i] = v2f{(float)tab->dft128_cos[i], (float)tab->dft128_sin[i]};
     v2f h = {tab->pss_taps[n_id_2][i].re, tab->pss_taps[n_id_2][i].im};
     lt_.taps[i] = h;
   }
@@ -739,12 +775,11 @@ struct SssResult {
   float m0_value, m1_value;
 };
 
-// srslte_sss_m0m1_partial after the DFT: every wave combines the partial bins into sc.Y (all waves
-// write identical values), then lanes 0..30 correlate against the 31 shifts.  Wave-uniform result.
+// srslte_sss_m0m1_partial after the FFT (bins in sc.Y): two lanes per shift correlate against the 31
+// shifts of s~.  Wave-uniform result.
 __device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_, SssResult &r)
 {
   const int lane = threadIdx.x & 63;
-  if (lane < 62) sc.Y[lane] = sss_dft_combine(sc.Yp[lane]);
   const int m = lane & 31, half = lane >> 5;
   const uint32_t s_rot = rot31(lt_.s_mask, m < 31 ? m : 0);
   float corr = sss_corr(sc.Y, 0, s_rot ^ lt_.c0_mask, half);
@@ -754,38 +789,19 @@ __device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_,
 }
 
 // sss_impl::work body after the tag check (lib/sss_impl.cc:102-150) on S = corrected half-frame
-// samples [480, 960) in LDS.  Block-wide (needs >= 496 threads for the DFT); one barrier inside.
-// The CP decision is cheap and made by every wave for itself; the m0/m1 search after the DFT runs
-// on wave 0 only -- its results are needed by nothing but the record thread 0 writes, so the
-// other waves move on (the returned m0/m1/n_id_1 are valid in wave 0 only).
-__device__ __forceinline__ SssResult sss_stage(const v2f *S, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
-                                              float &m_norm_avg, float &m_ext_avg, Scratch &sc,
-                                              unsigned long long *prof = nullptr)
+// samples [480, 960) in LDS, executed by ONE wave (no block barrier inside): CP decision, FFT-128 of
+// the SSS symbol, m0/m1 search, N_id_1.  Its results feed nothing but the record and the CP
+// averages, both owned by that wave.
+__device__ __forceinline__ SssResult sss_stage_wave(const v2f *S, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
+                                                   float &m_norm_avg, float &m_ext_avg, Scratch &sc)
 {
-  const int tid = threadIdx.x;
-  unsigned long long ts_ = prof ? __builtin_amdgcn_s_memtime() : 0;
-#define LT_SSTAMP(i)                                             \
-  if (prof) {                                                    \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    prof[i] += t_ - ts_;                                         \
-    ts_ = t_;                                                    \
-  }
   SssResult r;
-  r.m0 = r.m1 = r.n_id_1 = -1;
-  r.m0_value = r.m1_value = 0.f;
   r.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg);
-  LT_SSTAMP(17)
   const int cp_len = (r.cp == LT_CP_NORM) ? 9 : 32;                 // srslte_sync_set_cp
   const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len - kSssBase; // lib/sss_impl.cc:110
-  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S + sss_idx, tid >> 3, tid & 7, lt_.tw128);
-  LT_SSTAMP(18)
-  __syncthreads();
-  LT_SSTAMP(19)
-  if (tid < 64) {
-    sss_m0m1_wave(sc, lt_, r);
-    r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
-  }
-  LT_SSTAMP(20)
+  sss_fft128_wave(S + sss_idx, lt_.tw128, sc.Y);
+  sss_m0m1_wave(sc, lt_, r);
+  r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
   return r;
 }
 

@@ -203,7 +203,9 @@ template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kerne
           const float c = cfo_estimate_wave(ltab.taps, RAW + (kSlotLen - kSymbolSz - kSssBase));
           LT_TSTAMP(9) // cfo estimate (wave 0)
           const uint32_t slot = cfo_i % kMovingAvgSz;
-          const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c, &sc.ring_sum, profp ? &prof[22] : nullptr);
+          const float mc = (kDiag && (a.ablate & 32))
+                               ? c
+                               : moving_avg_wave(cfo_data, cfo_i + 1, slot, c, profp ? &prof[22] : nullptr);
           LT_TSTAMP(21) // ring mean (wave 0)
           if (tid == 0) {
             cfo_data[slot] = c;
@@ -228,7 +230,11 @@ template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kerne
         // srslte_pss_chest (lib/pss_impl.cc:206-209): its output is never consumed -- dropped.
 
         // ---- sss_impl::work, no tracking_lost tag on this half-frame (lib/sss_impl.cc:102-150)
-        const SssResult s = sss_stage(S, ltab, tab, m_norm_avg, m_ext_avg, sc, profp);
+        // (wave 0 only: m0, m1, n_id_1 and the CP averages feed nothing but the record and the
+        // state thread 0 stores; the other waves run ahead to the next barrier)
+        SssResult s;
+        s.cp = LT_CP_NORM; s.m0 = -1; s.m1 = -1; s.n_id_1 = -1; s.m0_value = s.m1_value = 0.f;
+        if (tid < 64 && !(kDiag && (a.ablate & 64))) s = sss_stage_wave(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
         LT_TSTAMP(12) // sss stage
         if (profp) prof[13] += 1;
         flags |= LT_F_SSS_RAN;
@@ -374,7 +380,7 @@ struct M0M1Result {
   float m0_value, m1_value;
 };
 
-__global__ __launch_bounds__(512) void lt_sss_m0m1_kernel(const v2f *__restrict__ sym,
+__global__ __launch_bounds__(128) void lt_sss_m0m1_kernel(const v2f *__restrict__ sym,
                                                           const DeviceTables *__restrict__ tab, int n_id_2,
                                                           M0M1Result *res)
 {
@@ -385,10 +391,11 @@ __global__ __launch_bounds__(512) void lt_sss_m0m1_kernel(const v2f *__restrict_
   load_lds_tables(ltab, tab, n_id_2);
   if (tid < kSymbolSz) S[tid] = sym[tid];
   __syncthreads();
-  if (tid < 62 * 8) sc.Yp[tid >> 3][tid & 7] = sss_dft_partial(S, tid >> 3, tid & 7, ltab.tw128);
-  __syncthreads();
   SssResult r;
-  sss_m0m1_wave(sc, ltab, r);
+  if (tid < 64) {
+    sss_fft128_wave(S, ltab.tw128, sc.Y);
+    sss_m0m1_wave(sc, ltab, r);
+  }
   if (tid == 0) {
     res->m0 = r.m0; res->m1 = r.m1; res->m0_value = r.m0_value; res->m1_value = r.m1_value;
   }
@@ -499,7 +506,7 @@ hipError_t launch_detect_cp(const void *in, int peak_pos, void *sync_state, int 
 hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2, void *res,
                            hipStream_t stream)
 {
-  hipLaunchKernelGGL(lt_sss_m0m1_kernel, dim3(1), dim3(512), 0, stream,
+  hipLaunchKernelGGL(lt_sss_m0m1_kernel, dim3(1), dim3(128), 0, stream,
                      reinterpret_cast<const v2f *>(sym), tab, n_id_2,
                      reinterpret_cast<M0M1Result *>(res));
   return hipGetLastError();

@@ -320,18 +320,20 @@ int orc_pss_find_pss(orc_pss_t *q, const orc_cf *in, float *psr)
 float orc_pss_cfo_compute(const orc_pss_t *q, const orc_cf *r)
 {
   /* srslte_vec_dot_prod_ccc (no conjugate) is a SIMD kernel in srsLTE: lane-wise partial sums
-   * followed by a horizontal add.  Restated with four interleaved partial sums per half
-   * (m mod 4), combined as (p0+p1)+(p2+p3); the kernels use the same order. */
+   * followed by a horizontal add.  Restated with eight interleaved partial sums per half
+   * (m mod 8), combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)); the kernels use the same order. */
   orc_cf y[2];
   for (int half = 0; half < 2; half++) {
-    orc_cf p[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    for (int j = 0; j < 16; j++)
-      for (int l = 0; l < 4; l++) {
-        const int m = 64 * half + 4 * j + l;
+    orc_cf p[8];
+    for (int l = 0; l < 8; l++) p[l] = cf(0.f, 0.f);
+    for (int j = 0; j < 8; j++)
+      for (int l = 0; l < 8; l++) {
+        const int m = 64 * half + 8 * j + l;
         orc_cf t = cmul(q->h[m], r[m]);
         p[l].re += t.re; p[l].im += t.im;
       }
-    y[half] = cf((p[0].re + p[1].re) + (p[2].re + p[3].re), (p[0].im + p[1].im) + (p[2].im + p[3].im));
+    y[half] = cf(((p[0].re + p[1].re) + (p[2].re + p[3].re)) + ((p[4].re + p[5].re) + (p[6].re + p[7].re)),
+                 ((p[0].im + p[1].im) + (p[2].im + p[3].im)) + ((p[4].im + p[5].im) + (p[6].im + p[7].im)));
   }
   const orc_cf y0 = y[0], y1 = y[1];
   /* carg(conjf(y0)*y1)/M_PI: float product, double atan2 */
@@ -457,31 +459,43 @@ int orc_sync_detect_cp(orc_sync_t *q, const orc_cf *in, int peak_pos)
 void orc_sss_m0m1(const orc_sync_t *q, const orc_cf *sym, int *m0, float *m0_value, int *m1,
                   float *m1_value)
 {
-  /* 128-point forward DFT (single precision like srsLTE's FFTW3F plan), centred output with DC
-   * removed: 62 bins -31..-1,+1..+31.  Each bin is eight interleaved partial sums (n mod 8)
-   * combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)); the kernels use the same order. */
-  static float twc[128], tws[128];
+  /* 128-point forward DFT in single precision (srsLTE: FFTW3F plan, mirror + dc): iterative
+   * radix-2 decimation-in-time FFT, bit-reversed input order, butterflies
+   *   t = w * b = (b.re w.re - b.im w.im, b.re w.im + b.im w.re);  a' = a + t;  b' = a - t
+   * with w = W128^(k * 128/len) from a float table.  Centred output with DC removed: 62 bins
+   * -31..-1, +1..+31.  The kernels evaluate the same butterflies (one pair of points per lane). */
+  static float twc[64], tws[64];
   static int tw_ready;
   if (!tw_ready) {
-    for (int e = 0; e < 128; e++) {
+    for (int e = 0; e < 64; e++) {
       double ph = -2.0 * M_PI * (double)e / 128.0;
       twc[e] = (float)cos(ph);
       tws[e] = (float)sin(ph);
     }
     tw_ready = 1;
   }
+  orc_cf a[128];
+  for (int i = 0; i < 128; i++) {
+    int r = 0;
+    for (int b = 0; b < 7; b++)
+      if (i & (1 << b)) r |= 1 << (6 - b);
+    a[i] = sym[r];
+  }
+  for (int len = 2; len <= 128; len <<= 1) {
+    const int half = len >> 1, step = 128 / len;
+    for (int i = 0; i < 128; i += len)
+      for (int k = 0; k < half; k++) {
+        const float wr = twc[k * step], wi = tws[k * step];
+        const orc_cf u = a[i + k], v = a[i + k + half];
+        const float tr = v.re * wr - v.im * wi, ti = v.re * wi + v.im * wr;
+        a[i + k] = cf(u.re + tr, u.im + ti);
+        a[i + k + half] = cf(u.re - tr, u.im - ti);
+      }
+  }
   orc_cf Y[62];
   for (int k = 0; k < 62; k++) {
     int bin = (k < 31) ? (k - 31) : (k - 30);
-    float pr[8] = {0}, pi[8] = {0};
-    for (int n = 0; n < 128; n++) {
-      const int e = (bin * n) & 127;
-      const float c = twc[e], sn = tws[e];
-      pr[n & 7] += sym[n].re * c - sym[n].im * sn;
-      pi[n & 7] += sym[n].re * sn + sym[n].im * c;
-    }
-    Y[k] = cf(((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])),
-              ((pi[0] + pi[1]) + (pi[2] + pi[3])) + ((pi[4] + pi[5]) + (pi[6] + pi[7])));
+    Y[k] = a[(bin + 128) & 127];
   }
   orc_cf y0[31], y1[31];
   for (int i = 0; i < 31; i++) {

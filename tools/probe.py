@@ -16,7 +16,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mode", default="noise", choices=["noise", "clean", "mix", "decim"])
-    ap.add_argument("--ablate", type=int, default=0, help="1 no window load, 2 no conv, 4 no reductions")
+    ap.add_argument("--ablate", type=int, default=0,
+                    help="1 no window load, 2 no conv, 4 no reductions, 8 stamps, 16 direct-form filter, 32 no ring mean, 64 no sss stage")
+    ap.add_argument("--threshold", type=float, default=4.0)
     args = ap.parse_args()
     import torch
     import ltetrigger_amd as lt
@@ -49,7 +51,7 @@ def main():
         iq, _ = bench.make_channels(torch, frames, args.channels, n, 0, 20.0, dev)
     iqr = torch.view_as_real(iq).contiguous()
     torch.cuda.synchronize()
-    b = lt.Batch(args.channels, n)
+    b = lt.Batch(args.channels, n, psr_threshold=args.threshold)
     if args.ablate:
         import ctypes
         lt.lib().lt_debug_set_ablation(b._h, ctypes.c_int(args.ablate))
