@@ -40,7 +40,7 @@ EXPORTS = [
     "lt_sync_init", "lt_sync_set_N_id_2", "lt_sync_free", "lt_sync_reset", "lt_sync_detect_cp",
     "lt_sync_set_cp", "lt_sync_get_cp_len", "lt_sync_get_cp_metrics", "lt_sss_m0m1_partial",
     "lt_sss_N_id_1", "lt_sync_get_cell_id",
-    "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_psr_threshold",
+    "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
     "lt_batch_get_halfframes", "lt_batch_last_kernel_ms",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
@@ -105,6 +105,7 @@ def lib():
     L.lt_batch_free.argtypes = [vp]
     L.lt_batch_free.restype = None
     L.lt_batch_reset.argtypes = [vp]
+    L.lt_batch_set_mode.argtypes = [vp, i32]
     L.lt_batch_set_psr_threshold.argtypes = [vp, f32]
     L.lt_batch_run.argtypes = [vp, vp, i32, i64, vp]
     L.lt_batch_collect.argtypes = [vp, vp, i64, vp]
@@ -304,6 +305,10 @@ class Batch:
 
     def set_psr_threshold(self, t):
         _check(lib().lt_batch_set_psr_threshold(self._h, t), "lt_batch_set_psr_threshold")
+
+    def set_mode(self, mode):
+        """1 = bulk metric kernel + replay kernel (default), 0 = fused per-chain kernel."""
+        _check(lib().lt_batch_set_mode(self._h, int(mode)), "lt_batch_set_mode")
 
     def enable_halfframes(self, max_per_chain):
         _check(lib().lt_batch_enable_halfframes(self._h, int(max_per_chain)), "lt_batch_enable_halfframes")

@@ -144,6 +144,8 @@ struct lt_batch {
   int rec_cap = 0;
   lt_cf32 *d_hf = nullptr;
   int64_t hf_cap = 0;
+  float *d_metric = nullptr; // bulk + replay mode: [3][n_channels][max_samples]
+  int mode = 1;              // 0 fused chain kernel, 1 bulk metric kernel + replay kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ran = false;
   int ablate = 0;
@@ -517,6 +519,7 @@ void lt_batch_free(lt_batch *b)
   if (b->d_recs) (void)hipFree(b->d_recs);
   if (b->d_count) (void)hipFree(b->d_count);
   if (b->d_hf) (void)hipFree(b->d_hf);
+  if (b->d_metric) (void)hipFree(b->d_metric);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -593,6 +596,13 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   L.track_every = b->params.track_every;
   L.ablate = b->ablate;
   L.prof = b->d_prof;
+  if (b->mode == 1 && (!b->ablate || (b->ablate & 128))) { // 128: diagnostics build of the replay kernel
+    if (!b->d_metric)
+      HIP_TRY(hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples));
+    L.metric = b->d_metric;
+    L.metric_ch_stride = b->max_samples;
+    L.metric_root_stride = (int64_t)b->n_channels * b->max_samples;
+  }
   HIP_TRY(hipEventRecord(b->ev0, s));
   HIP_TRY(lt::launch_chain(L, s));
   HIP_TRY(hipEventRecord(b->ev1, s));
@@ -658,6 +668,15 @@ int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, i
   if (n > 0 && out)
     HIP_TRY(hipMemcpy(out, b->d_hf + (size_t)chain * (size_t)b->hf_cap * LT_HALF_FRAME_LEN,
                       sizeof(lt_cf32) * LT_HALF_FRAME_LEN * (size_t)n, hipMemcpyDeviceToHost));
+  return LT_OK;
+}
+
+// 0 = fused chain kernel (window filter inside the per-chain workgroup), 1 = bulk metric kernel +
+// replay kernel (default).  Both give the same records up to the 1e-6 rounding of the lag metric.
+int lt_batch_set_mode(lt_batch *b, int mode)
+{
+  if (!b || (mode != 0 && mode != 1)) return fail(LT_ERROR_INVALID_INPUTS, "mode must be 0 or 1");
+  b->mode = mode;
   return LT_OK;
 }
 

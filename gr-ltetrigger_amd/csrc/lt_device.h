@@ -268,6 +268,9 @@ struct FilterLds {
   const v2f *spec; // filter spectrum / 1024, natural order, in LDS
 };
 
+__device__ __forceinline__ void search_ema(const float met[kT], float *AVG, float ema[kT], Scratch &sc, int ablate,
+                                           unsigned long long *prof);
+
 __device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
                                              const v2f *__restrict__ taps, const FilterLds &fl, Scratch &sc,
                                              int ablate, unsigned long long *prof = nullptr)
@@ -291,6 +294,18 @@ __device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
 #pragma unroll
     for (int t = 0; t < kT; ++t) met[t] = AVG[n0 + t];
   }
+  LT_STAMP(0) // matched filter
+  search_ema(met, AVG, ema, sc, ablate, prof);
+}
+
+// EMA of the lag metric (three roundings like srsLTE's three vector passes), LDS mirror, per-thread
+// maxima; ends with the block-wide barrier.  met[t] = |conv|^2 of lag 19 tid + t.
+__device__ __forceinline__ void search_ema(const float met[kT], float *AVG, float ema[kT], Scratch &sc, int ablate,
+                                           unsigned long long *prof)
+{
+  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+  const int tid = threadIdx.x;
+  const int n0 = tid * kT;
   if (ablate & 4) { // diagnostics: no reductions
     float s = 0.f;
 #pragma unroll
@@ -302,9 +317,7 @@ __device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
     __syncthreads();
     return;
   }
-
-  LT_STAMP(0) // matched filter
-  // |conv|^2, EMA with three roundings like srsLTE's three vector passes, local first-maximum
+  // EMA with three roundings like srsLTE's three vector passes, local first-maximum
   float bv = -FLT_MAX;
   int bi = INT_MAX;
 #pragma unroll
@@ -431,6 +444,48 @@ __device__ __forceinline__ SearchResult search_window(v2f *W, float *AVG, float 
 {
   search_front(W, AVG, ema, taps, fl, sc, ablate);
   return search_tail(AVG, sc, ablate);
+}
+
+// ---- bulk + replay mode: the interior lags 127..9599 of a window come from the position-independent
+// metric P[pos + lag] computed once per channel by lt_metric_kernel; only the 253 edge lags, whose
+// convolution sums are cut by the window's zero padding, are recomputed here.
+//   head lag j      (j = 0..126): sum_{m=0}^{j}     h[m] x[pos + j - m]
+//   tail lag 9600+j (j = 0..125): sum_{m=j+1}^{127} h[m] x[pos + 9600 + j - m]
+// With Z = [ x[pos+9472 .. pos+9600) | x[pos .. pos+128) ] (256 samples staged in LDS by the caller)
+// both sums read Z[128 + j - m]: taps m <= j fall into the head half, the others into the tail half,
+// so "unit" j walks all 128 taps once and yields head lag j and tail lag 9600+j.  Four lanes share a
+// unit, taps m = q, q+4, q+8, ... each (fixed trip count: the LDS loads batch; neighbouring lanes
+// read neighbouring or identical words: no bank conflicts); a lane's accumulator is moved aside
+// where its taps cross from head to tail; the four partial sums meet in an xor butterfly.
+// Items first, first+stride, ... < 512 are processed (item = 4 * unit + q).
+__device__ __forceinline__ void edge_lags(const v2f *Z, const v2f *taps, float *metric, int first, int stride)
+{
+  for (int item = first; item < 512; item += stride) { // trip count must be wave-uniform (DPP below)
+    const int j_raw = item >> 2, q = item & 3;
+    const int j = j_raw < 127 ? j_raw : 126; // items 508..511 are padding
+    const int b = (j - q + 4) >> 2;          // leading taps of this lane (m = q + 4 i <= j) that are head taps
+    const v2f *zp = Z + 128 + j - q;         // sample of tap q + 4 i = zp[-4 i]
+    const v2f *hp = taps + q;
+    float re = 0.f, im = 0.f, hre = 0.f, him = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const v2f h = hp[4 * i], z = zp[-4 * i];
+      re = fmaf(h.x, z.x, re);
+      re = fmaf(-h.y, z.y, re);
+      im = fmaf(h.x, z.y, im);
+      im = fmaf(h.y, z.x, im);
+      if (i + 1 == b) { // last head tap of the range: what follows belongs to the tail lag
+        hre = re; him = im;
+        re = 0.f; im = 0.f;
+      }
+    }
+    hre += lane_xor<1>(hre); him += lane_xor<1>(him); re += lane_xor<1>(re); im += lane_xor<1>(im);
+    hre += lane_xor<2>(hre); him += lane_xor<2>(him); re += lane_xor<2>(re); im += lane_xor<2>(im);
+    if (q == 0 && j_raw < 127) {
+      metric[j] = __fadd_rn(__fmul_rn(hre, hre), __fmul_rn(him, him));
+      if (j < 126) metric[kHalfFrame + j] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    }
+  }
 }
 
 // copy the FFT twiddles and the filter spectrum of one root into LDS (2 x 8 KB)

@@ -28,26 +28,31 @@ struct ChainArgs {
   float psr_threshold;
   int track_after;
   int track_every;
+  const float *metric;    // bulk + replay mode: P[root][channel][pos] from lt_metric_kernel, else null
+  int64_t metric_ch_stride;   // floats between channels
+  int64_t metric_root_stride; // floats between roots
   int ablate;             // diagnostics only (tools/probe.py): 1 = skip the window load
   unsigned long long *prof; // diagnostics only: per-phase shader-clock sums of chain 0 (ablate & 8)
 };
 
 // kDiag = true is the diagnostics build (tools/probe.py: ablation switches, in-kernel stamps, the
 // direct-form filter); the product launches kDiag = false, where all of that folds away.
-template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a_in)
+template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a_in)
 {
   ChainArgs a = a_in;
   if (!kDiag) {
     a.ablate = 0;
     a.prof = nullptr;
   }
-  __shared__ v2f W[kWLen];
+  // fused mode: window buffer (also FFT scratch), twiddles and filter spectrum; replay mode: only the
+  // 2 x 128 edge samples of the window
+  __shared__ v2f W[kBulk ? 256 : kWLen];
   __shared__ float AVG[kAvgLen];
   __shared__ v2f S[kSssLen];
   __shared__ v2f RAW[kSssLen];
   __shared__ LdsTables ltab;
-  __shared__ v2f TW[fft::kN];
-  __shared__ v2f SPEC[fft::kN];
+  __shared__ v2f TW[kBulk ? 1 : fft::kN];
+  __shared__ v2f SPEC[kBulk ? 1 : fft::kN];
   __shared__ float psr_data[kMovingAvgSz];
   __shared__ float cfo_data[kMovingAvgSz];
   __shared__ Scratch sc;
@@ -75,8 +80,9 @@ template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kerne
   }
   if (tid < kAvgLen - kConvLen) AVG[kConvLen + tid] = 0.f;
   load_lds_tables(ltab, tab, n_id_2);
-  load_filter_lds(TW, SPEC, tab, n_id_2);
+  if (!kBulk) load_filter_lds(TW, SPEC, tab, n_id_2);
   const FilterLds fl = {TW, SPEC};
+  const float *__restrict__ P = kBulk ? a.metric + n_id_2 * a.metric_root_stride + channel * a.metric_ch_stride : nullptr;
   int64_t pos = 0; // every run starts at sample 0 of the capture handed to it
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
@@ -86,10 +92,14 @@ template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kerne
   float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
   int nrec = 0;
   const int call_base = st->n_calls;
-  v2f pf[kT];          // next window, prefetched (19 * 512 = 9728 >= 9600 samples)
-  int64_t pf_pos = -1; // stream position the prefetch belongs to, -1 = none
+  v2f pf[kBulk ? 1 : kT]; // fused mode: next window, prefetched (19 * 512 = 9728 >= 9600 samples)
+  float pfm[kBulk ? kT : 1]; // replay mode: next window's interior metric slice
+  v2f pfe = {0.f, 0.f};      // replay mode: one of the next window's 256 edge samples (tid < 256)
+  int64_t pf_pos = -1;       // stream position the prefetch belongs to, -1 = none
 #pragma unroll
-  for (int i = 0; i < kT; ++i) pf[i] = v2f{0.f, 0.f};
+  for (int i = 0; i < (kBulk ? 1 : kT); ++i) pf[i] = v2f{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < (kBulk ? kT : 1); ++i) pfm[i] = 0.f;
   unsigned long long prof[24] = {0};
   unsigned long long *profp = (kDiag && (a.ablate & 8) && a.prof) ? prof : nullptr;
   __syncthreads();
@@ -102,32 +112,69 @@ template <bool kDiag> __global__ __launch_bounds__(kThreads) void lt_chain_kerne
     if (!is_tracking || timer == 0) {
       timer = a.track_every;
       unsigned long long t0_ = profp ? __builtin_amdgcn_s_memtime() : 0;
-      if (!(a.ablate & 1)) {
-        if (pf_pos == pos) { // prefetched under the previous search's tail
+      if (kBulk) {
+        // interior lags 127..9599 = position-independent metric; edges recomputed from the samples
+        if (pf_pos == pos) {
 #pragma unroll
           for (int i = 0; i < kT; ++i) {
-            const int k = tid + i * kThreads;
-            if (k < kHalfFrame) W[kWPad + k] = pf[i];
+            const int k = (kSymbolSz - 1) + tid + i * kThreads;
+            if (k < kHalfFrame) AVG[k] = pfm[i];
           }
+          if (tid < 256) W[tid] = pfe;
         } else {
-          for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+          for (int k = (kSymbolSz - 1) + tid; k < kHalfFrame; k += kThreads) AVG[k] = P[pos + k];
+          if (tid < 128) W[tid] = x[pos + kHalfFrame - 128 + tid]; // Z = [window tail | window head]
+          else if (tid < 256) W[tid] = x[pos - 128 + tid];
         }
-        // the zero pads around the window (the matched filter used W as scratch last time)
-        for (int i = tid; i < kWPad; i += kThreads) W[i] = v2f{0.f, 0.f};
-        for (int i = kWPad + kHalfFrame + tid; i < kWLen; i += kThreads) W[i] = v2f{0.f, 0.f};
-      }
-      __syncthreads();
-      if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // window load
-      search_front(W, AVG, ema, taps, fl, sc, a.ablate, profp);
-      // W is free from here on: start fetching the window a miss leads to (pos + 9600); the loads
-      // fly under the tail reductions and the state machine, a realigning hit discards them.
-      pf_pos = -1;
-      if (!(a.ablate & 1) && pos + 2 * kHalfFrame <= n) {
-        pf_pos = pos + kHalfFrame;
+        __syncthreads();
+        if (profp) prof[14] += __builtin_amdgcn_s_memtime() - t0_; // metric slice arrives
+        edge_lags(W, ltab.taps, AVG, tid, kThreads);
+        if (profp) prof[15] += __builtin_amdgcn_s_memtime() - t0_; // + edge lags
+        __syncthreads();
+        if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // metric load + edges
+        float met[kT];
 #pragma unroll
-        for (int i = 0; i < kT; ++i) {
-          const int k = tid + i * kThreads;
-          if (k < kHalfFrame) pf[i] = x[pf_pos + k];
+        for (int t = 0; t < kT; ++t) met[t] = AVG[tid * kT + t];
+        search_ema(met, AVG, ema, sc, a.ablate, profp);
+        pf_pos = -1;
+        if (pos + 2 * kHalfFrame <= n) { // prefetch what a miss leads to
+          pf_pos = pos + kHalfFrame;
+#pragma unroll
+          for (int i = 0; i < kT; ++i) {
+            const int k = (kSymbolSz - 1) + tid + i * kThreads;
+            if (k < kHalfFrame) pfm[i] = P[pf_pos + k];
+          }
+          if (tid < 128) pfe = x[pf_pos + kHalfFrame - 128 + tid];
+          else if (tid < 256) pfe = x[pf_pos - 128 + tid];
+        }
+      } else {
+        if (!(a.ablate & 1)) {
+          if (pf_pos == pos) { // prefetched under the previous search's tail
+#pragma unroll
+            for (int i = 0; i < (kBulk ? 1 : kT); ++i) {
+              const int k = tid + i * kThreads;
+              if (k < kHalfFrame) W[kWPad + k] = pf[i];
+            }
+          } else {
+            for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+          }
+          // the zero pads around the window (the matched filter used W as scratch last time)
+          for (int i = tid; i < kWPad; i += kThreads) W[i] = v2f{0.f, 0.f};
+          for (int i = kWPad + kHalfFrame + tid; i < kWLen; i += kThreads) W[i] = v2f{0.f, 0.f};
+        }
+        __syncthreads();
+        if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // window load
+        search_front(W, AVG, ema, taps, fl, sc, a.ablate, profp);
+        // W is free from here on: start fetching the window a miss leads to (pos + 9600); the loads
+        // fly under the tail reductions and the state machine, a realigning hit discards them.
+        pf_pos = -1;
+        if (!(a.ablate & 1) && pos + 2 * kHalfFrame <= n) {
+          pf_pos = pos + kHalfFrame;
+#pragma unroll
+          for (int i = 0; i < (kBulk ? 1 : kT); ++i) {
+            const int k = tid + i * kThreads;
+            if (k < kHalfFrame) pf[i] = x[pf_pos + k];
+          }
         }
       }
       const SearchResult r = search_tail(AVG, sc, a.ablate, profp);
@@ -433,6 +480,68 @@ __global__ __launch_bounds__(256) void lt_decim_kernel(const v2f *__restrict__ x
   y[(int64_t)c * n_out + k] = r;
 }
 
+// ---------------------------------------------------------------- bulk lag metric (bulk + replay mode)
+// P[root][channel][p] = | sum_m h_root[m] x[channel][p - m] |^2 for every sample position p (x[<0] = 0):
+// the position-independent part of srslte_pss_find_pss's convolution, for all three roots from ONE
+// forward FFT per 1024-sample overlap-save block (897 new positions per block).  One half-wave per
+// block, 16 blocks per workgroup; inputs come straight from HBM (32 x 256-byte rows per block),
+// outputs go back as 3 x 897 floats.  Algorithmic bytes: 8 B read + 12 B written per sample.
+struct MetricArgs {
+  const v2f *iq;   // [n_channels][ch_stride]
+  int64_t n_samples;
+  int64_t ch_stride;
+  int n_channels;
+  int blocks_per_channel; // ceil(n_samples / 897)
+  float *metric;   // [3][n_channels][metric_ch_stride]
+  int64_t metric_ch_stride;
+  int64_t metric_root_stride;
+  const DeviceTables *tab;
+};
+
+constexpr int kMetricThreads = 256;                 // 8 half-waves = 8 blocks per workgroup, two workgroups per CU
+constexpr int kMetricBlocks = kMetricThreads / 32;
+
+template <int kAbl> __global__ __launch_bounds__(kMetricThreads, 2) void lt_metric_kernel(MetricArgs a)
+{
+  __shared__ v2f E[kMetricBlocks * fft::kScratch]; // one exchange area per half-wave (67.6 KB)
+  __shared__ v2f TW[fft::kN];
+  const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+  for (int i = tid; i < fft::kN; i += kMetricThreads) TW[i] = v2f{a.tab->fft_tw[i].re, a.tab->fft_tw[i].im};
+  __syncthreads();
+  const int64_t g = (int64_t)blockIdx.x * kMetricBlocks + hw; // global block index
+  const int64_t total = (int64_t)a.n_channels * a.blocks_per_channel;
+  if (g >= total) return; // whole half-wave leaves together; no barrier follows
+  const int ch = (int)(g / a.blocks_per_channel);
+  const int64_t j = g % a.blocks_per_channel;
+  const v2f *__restrict__ x = a.iq + (int64_t)ch * a.ch_stride;
+  const int64_t base = j * kBlkValid - (kSymbolSz - 1); // first input sample of the block
+  fft::c32 xf[32], v[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) xf[r] = (kAbl & 2) ? fft::c32{(float)(l + r), (float)g} : ld_iq(x, a.n_samples, base + l + 32 * r);
+  fft::c32 *e = E + hw * fft::kScratch;
+  fft::fft1024_stage1<false>(l, xf, TW, e);
+  fft::fft1024_stage2<false>(l, xf, e);
+#pragma unroll 1
+  for (int root = 0; root < ((kAbl & 4) ? 1 : 3); ++root) {
+    const cf32 *__restrict__ spec = a.tab->pss_spec[root];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const cf32 h = spec[r * 32 + l];
+      v[r] = fft::cmul<false>(xf[r], fft::c32{h.re, h.im});
+    }
+    fft::fft1024_stage1<true>(l, v, TW, e);
+    fft::fft1024_stage2<true>(l, v, e);
+    float *__restrict__ out = a.metric + root * a.metric_root_stride + ch * a.metric_ch_stride;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const int i = l + 32 * r;
+      const int64_t p = base + i;
+      if (i >= kSymbolSz - 1 && p < a.n_samples && (!(kAbl & 1) || v[r].x == 1234.5f))
+        out[p] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+    }
+  }
+}
+
 } // namespace lt
 
 // Host-callable launchers (the C-ABI in lt_api.cpp only sees these).
@@ -459,10 +568,41 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
   a.track_every = L.track_every;
   a.ablate = L.ablate;
   a.prof = reinterpret_cast<unsigned long long *>(L.prof);
-  if (L.ablate)
-    hipLaunchKernelGGL(lt_chain_kernel<true>, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
-  else
-    hipLaunchKernelGGL(lt_chain_kernel<false>, dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  a.metric = L.metric;
+  a.metric_ch_stride = L.metric_ch_stride;
+  a.metric_root_stride = L.metric_root_stride;
+  if (L.metric) {
+    MetricArgs m;
+    m.iq = a.iq;
+    m.n_samples = L.n_samples;
+    m.ch_stride = L.ch_stride;
+    m.n_channels = L.n_channels;
+    m.blocks_per_channel = (int)((L.n_samples + kBlkValid - 1) / kBlkValid);
+    m.metric = L.metric;
+    m.metric_ch_stride = L.metric_ch_stride;
+    m.metric_root_stride = L.metric_root_stride;
+    m.tab = L.tab;
+    const int64_t total = (int64_t)m.n_channels * m.blocks_per_channel;
+    if (total > 0) {
+      const unsigned grid = (unsigned)((total + kMetricBlocks - 1) / kMetricBlocks);
+      static const int abl = getenv("LT_METRIC_ABL") ? atoi(getenv("LT_METRIC_ABL")) : 0;
+      switch (abl) {
+      case 1: hipLaunchKernelGGL(lt_metric_kernel<1>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
+      case 2: hipLaunchKernelGGL(lt_metric_kernel<2>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
+      case 3: hipLaunchKernelGGL(lt_metric_kernel<3>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
+      case 4: hipLaunchKernelGGL(lt_metric_kernel<4>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
+      case 7: hipLaunchKernelGGL(lt_metric_kernel<7>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
+      default: hipLaunchKernelGGL(lt_metric_kernel<0>, dim3(grid), dim3(kMetricThreads), 0, stream, m);
+      }
+    }
+    if (L.ablate) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+    else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  } else if (L.ablate) {
+    a.metric = nullptr;
+    hipLaunchKernelGGL((lt_chain_kernel<true, false>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((lt_chain_kernel<false, false>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+  }
   return hipGetLastError();
 }
 

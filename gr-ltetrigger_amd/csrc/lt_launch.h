@@ -25,6 +25,9 @@ struct ChainLaunch {
   float psr_threshold;
   int track_after;
   int track_every;
+  float *metric = nullptr;        // device, [3][n_channels][metric_ch_stride]: bulk + replay mode when set
+  int64_t metric_ch_stride = 0;
+  int64_t metric_root_stride = 0;
   int ablate = 0;       // diagnostics only
   void *prof = nullptr; // diagnostics only: 8 x uint64 on the device
 };

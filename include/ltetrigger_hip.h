@@ -166,6 +166,10 @@ int lt_batch_create(lt_batch **b, int device, int n_channels, int64_t max_sample
 void lt_batch_free(lt_batch *b);
 /* All chains back to their constructor state. */
 int lt_batch_reset(lt_batch *b);
+/* Execution strategy of lt_batch_run: 1 (default) = one bulk kernel computes the position-independent
+ * lag metric of every channel for all three roots, a light per-chain kernel replays the windows;
+ * 0 = everything fused in the per-chain kernel.  Same records (lag metric equal to ~1e-6). */
+int lt_batch_set_mode(lt_batch *b, int mode);
 /* downlink_trigger_c.set_psr_threshold fan-out (python/downlink_trigger_c.py:63-69) */
 int lt_batch_set_psr_threshold(lt_batch *b, float threshold);
 /* Run every chain over iq = [n_channels][n_samples] cf32 (channel-major, contiguous).

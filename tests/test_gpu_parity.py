@@ -142,10 +142,18 @@ def test_decimator_bit_exact(lt, oracle, decim):
 
 
 def _run_both(lt, oracle, iq, **kw):
+    """Both execution strategies of the batch (bulk + replay, fused) against the oracle; returns the
+    default (bulk + replay) results after checking that the fused kernel agrees with the oracle too."""
+    want = oracle.batch_run(iq, nthreads=8, **kw)
+    bf = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+    bf.set_mode(0)
+    bf.run_host(iq)
+    fused = bf.collect()
+    for c in range(len(want)):
+        assert_records_match(fused[c], want[c], f"fused kernel, chain {c}")
     b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
     b.run_host(iq)
     got = b.collect()
-    want = oracle.batch_run(iq, nthreads=8, **kw)
     return b, got, want
 
 

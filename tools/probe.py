@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0,
                     help="1 no window load, 2 no conv, 4 no reductions, 8 stamps, 16 direct-form filter, 32 no ring mean, 64 no sss stage")
     ap.add_argument("--threshold", type=float, default=4.0)
+    ap.add_argument("--fused", action="store_true", help="fused per-chain kernel instead of bulk + replay")
     args = ap.parse_args()
     import torch
     import ltetrigger_amd as lt
@@ -52,6 +53,8 @@ def main():
     iqr = torch.view_as_real(iq).contiguous()
     torch.cuda.synchronize()
     b = lt.Batch(args.channels, n, psr_threshold=args.threshold)
+    if args.fused:
+        b.set_mode(0)
     if args.ablate:
         import ctypes
         lt.lib().lt_debug_set_ablation(b._h, ctypes.c_int(args.ablate))
