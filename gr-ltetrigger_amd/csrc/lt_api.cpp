@@ -39,6 +39,7 @@ int fail(int code, const char *fmt, ...)
 // Constant tables, uploaded once per device and shared by every handle on it.
 struct DeviceCtx {
   lt::DeviceTables *d_tab = nullptr;
+  int n_cus = 0;
 };
 std::mutex g_ctx_mu;
 std::map<int, DeviceCtx> g_ctx;
@@ -74,6 +75,7 @@ int get_tables(int device, const lt::DeviceTables **out)
     delete host;
     if (e != hipSuccess) return fail(LT_ERROR, "uploading tables failed: %s", hipGetErrorString(e));
     c.d_tab = d;
+    c.n_cus = prop.multiProcessorCount;
   }
   *out = c.d_tab;
   return LT_OK;
@@ -145,6 +147,7 @@ struct lt_batch {
   lt_cf32 *d_hf = nullptr;
   int64_t hf_cap = 0;
   float *d_metric = nullptr; // bulk + replay mode: [3][n_channels][max_samples]
+  float *d_edge = nullptr;   // bulk + replay mode: [3][n_channels][max_samples / 9600][256]
   int mode = 1;              // 0 fused chain kernel, 1 bulk metric kernel + replay kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ran = false;
@@ -520,6 +523,7 @@ void lt_batch_free(lt_batch *b)
   if (b->d_count) (void)hipFree(b->d_count);
   if (b->d_hf) (void)hipFree(b->d_hf);
   if (b->d_metric) (void)hipFree(b->d_metric);
+  if (b->d_edge) (void)hipFree(b->d_edge);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -595,11 +599,20 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   L.track_after = b->params.track_after;
   L.track_every = b->params.track_every;
   L.ablate = b->ablate;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    L.n_cus = g_ctx[b->device].n_cus > 0 ? g_ctx[b->device].n_cus : 256;
+  }
   L.prof = b->d_prof;
   if (b->mode == 1 && (!b->ablate || (b->ablate & 128))) { // 128: diagnostics build of the replay kernel
     if (!b->d_metric)
       HIP_TRY(hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples));
     L.metric = b->d_metric;
+    const size_t max_windows = (size_t)b->max_samples / 9600 + 1;
+    if (!b->d_edge) HIP_TRY(hipMalloc(&b->d_edge, sizeof(float) * 3 * (size_t)b->n_channels * max_windows * 256));
+    L.edge = b->d_edge;
+    L.edge_ch_stride = (int64_t)max_windows * 256;
+    L.edge_root_stride = (int64_t)b->n_channels * L.edge_ch_stride;
     L.metric_ch_stride = b->max_samples;
     L.metric_root_stride = (int64_t)b->n_channels * b->max_samples;
   }

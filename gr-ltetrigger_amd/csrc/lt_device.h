@@ -25,6 +25,7 @@ namespace lt {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512;
+constexpr int kThreadsReplay = 256; // workgroup of the replay kernel (bulk + replay mode)
 constexpr int kWaves = kThreads / 64;
 constexpr int kT = 19;                              // lags per thread
 constexpr int kWPad = 128;                          // zero samples in front of the window in LDS
@@ -458,7 +459,7 @@ __device__ __forceinline__ SearchResult search_window(v2f *W, float *AVG, float 
 // read neighbouring or identical words: no bank conflicts); a lane's accumulator is moved aside
 // where its taps cross from head to tail; the four partial sums meet in an xor butterfly.
 // Items first, first+stride, ... < 512 are processed (item = 4 * unit + q).
-__device__ __forceinline__ void edge_lags(const v2f *Z, const v2f *taps, float *metric, int first, int stride)
+__device__ __forceinline__ void edge_lags(const v2f *Z, const v2f *taps, float *head, float *tail, int first, int stride)
 {
   for (int item = first; item < 512; item += stride) { // trip count must be wave-uniform (DPP below)
     const int j_raw = item >> 2, q = item & 3;
@@ -482,11 +483,158 @@ __device__ __forceinline__ void edge_lags(const v2f *Z, const v2f *taps, float *
     hre += lane_xor<1>(hre); him += lane_xor<1>(him); re += lane_xor<1>(re); im += lane_xor<1>(im);
     hre += lane_xor<2>(hre); him += lane_xor<2>(him); re += lane_xor<2>(re); im += lane_xor<2>(im);
     if (q == 0 && j_raw < 127) {
-      metric[j] = __fadd_rn(__fmul_rn(hre, hre), __fmul_rn(him, him));
-      if (j < 126) metric[kHalfFrame + j] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+      head[j] = __fadd_rn(__fmul_rn(hre, hre), __fmul_rn(him, him));                 // lag j
+      if (j < 126) tail[j] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));        // lag 9600 + j
     }
   }
 }
+
+// ---- bulk + replay mode search: srslte_pss_find_pss downstream of the lag metric with the lags
+// dealt out round-robin (thread t owns lags t, t + NT, t + 2 NT, ...), which is the order the
+// metric slice arrives in from HBM, so nothing is staged through LDS on the way in.
+template <int NT> struct BulkShared {
+  float tmax[2][NT]; // per-thread maximum of the EMA over its valid lags (two sets used in turn)
+  int tidx[2][NT];   // lag of that maximum
+  float edge[256];   // edge lags computed in the kernel: [0,127) head lags, [127,253) lags 9600..9725
+  float sl[NT / 64]; // wide main lobes only: per-wave side-lobe maxima
+};
+
+// EMA (three roundings like srsLTE's three vector passes), LDS mirror, per-thread first maximum.
+// No barrier inside: the caller issues its prefetch, then calls bulk_search_tail.
+template <int NT, int NL>
+__device__ __forceinline__ void bulk_search_ema(const float (&met)[NL], float (&ema)[NL], float *AVG, float *tmax, int *tidx)
+{
+  const int tid = threadIdx.x;
+  float bv = -FLT_MAX;
+  int bi = INT_MAX;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int lag = tid + i * NT;
+    if (lag < kNLags) {
+      ema[i] = __fadd_rn(__fmul_rn(met[i], 0.2f), __fmul_rn(ema[i], 1.0f - 0.2f));
+      if (ema[i] > bv) { // lags ascend with i: the first maximum of this thread
+        bv = ema[i];
+        bi = lag;
+      }
+    }
+    AVG[lag] = ema[i];
+  }
+  tmax[tid] = bv;
+  tidx[tid] = bi;
+}
+
+// arg-max, main-lobe walk, side lobes, PSR.  One block-wide barrier, after which every wave derives
+// the same (wave-uniform) results from LDS on its own.  `ema` = this thread's EMA values.
+//
+// Side lobes: srsLTE takes max(max over [0, pl_lb), max over [pl_ub, 9726)), an empty range standing
+// for the first element of where it would start (srslte_vec_max_fi returns index 0).  The maximum over
+// the lags outside the main lobe is assembled from the per-thread maxima: a thread whose maximum lies
+// outside the lobe contributes it as it is; the lags inside the lobe belong to pl_ub - pl_lb threads,
+// whose remaining lags are looked up in the LDS mirror one by one (a handful for the usual narrow
+// lobe; lobes wider than 64 lags take a second barrier and a masked pass over the registers instead).
+template <int NT, int NL>
+__device__ __forceinline__ SearchResult bulk_search_tail(const float (&ema)[NL], const float *AVG, const float *tmax,
+                                                         const int *tidx, float *wave_sl,
+                                                         unsigned long long *prof = nullptr)
+{
+  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define LT_BSTAMP(i)                                             \
+  if (prof) {                                                    \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    prof[i] += t_ - t_prev;                                      \
+    t_prev = t_;                                                 \
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  __syncthreads(); // AVG mirror and per-thread maxima visible
+  LT_BSTAMP(2) // barrier
+  float tv[NT / 64];
+  int ti[NT / 64];
+  float bv = -FLT_MAX;
+  int bi = INT_MAX;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) {
+    tv[k] = tmax[lane + 64 * k];
+    ti[k] = tidx[lane + 64 * k];
+    argmax_combine(bv, bi, tv[k], ti[k]);
+  }
+  {
+    const float wv = wave_max_f(bv);
+    const unsigned long long holders = __ballot(bv == wv);
+    if (__builtin_popcountll(holders) == 1) bi = __builtin_amdgcn_readlane(bi, __builtin_ctzll(holders)); // the usual case
+    else bi = wave_min_i(bv == wv ? bi : INT_MAX);
+  }
+  const int peak = (bi == INT_MAX) ? 0 : bi; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
+  const float peak_value = AVG[peak];
+  LT_BSTAMP(3) // arg-max
+
+  // main-lobe walk, 64 lags per step in each direction (see search_tail)
+  int pl_ub = 0, pl_lb = 0;
+  for (int base = peak + 1;; base += 64) {
+    const int u = base + lane;
+    bool stop = false;
+    if (u <= kConvLen - 1) stop = !(AVG[u + 1] <= AVG[u]) || u >= kConvLen - 1;
+    const unsigned long long m = __ballot(stop);
+    if (m) {
+      pl_ub = base + __builtin_ctzll(m);
+      break;
+    }
+  }
+  if (peak > 2) {
+    for (int base = peak - 1;; base -= 64) {
+      const int u = base - lane;
+      bool stop = false;
+      if (u >= 1) stop = !(AVG[u - 1] <= AVG[u]) || u <= 1;
+      const unsigned long long m = __ballot(stop);
+      if (m) {
+        pl_lb = base - __builtin_ctzll(m);
+        break;
+      }
+    }
+  }
+  const float q_left = AVG[0], q_right = AVG[pl_ub];
+  LT_BSTAMP(4) // walk
+  float out = -FLT_MAX; // maximum over the valid lags outside [pl_lb, pl_ub)
+  const int width = pl_ub - pl_lb;
+  if (width <= 64) {
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k)
+      if ((ti[k] < pl_lb || ti[k] >= pl_ub) && tv[k] > out) out = tv[k]; // (a thread without a maximum holds -FLT_MAX)
+    // the other lags of the threads that own the lobe's lags: candidate (lobe lag L, i) = (L mod 512) + 512 i
+    for (int c = lane; c < width * NL; c += 64) {
+      const int L = pl_lb + c / NL, i = c - (c / NL) * NL;
+      const int lag = (L & (NT - 1)) + i * NT;
+      if ((lag < pl_lb || lag >= pl_ub) && lag < kNLags) {
+        const float v = AVG[lag];
+        if (v > out) out = v;
+      }
+    }
+    out = wave_max_f(out);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int lag = tid + i * NT;
+      if ((lag < pl_lb || lag >= pl_ub) && lag < kNLags && ema[i] > out) out = ema[i];
+    }
+    out = wave_max_f(out);
+    if (lane == 0) wave_sl[tid >> 6] = out;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) {
+      const float o = wave_sl[k];
+      if (o > out) out = o;
+    }
+    __syncthreads(); // bs.sl may be rewritten by the next wide lobe
+  }
+  LT_BSTAMP(5) // side lobes
+  float sl = (pl_lb == 0) ? q_left : out, sr = (kNLags - pl_ub <= 0) ? q_right : out;
+  const float side = sl > sr ? sl : sr;
+  SearchResult r;
+  r.peak_pos = __builtin_amdgcn_readfirstlane(peak);
+  r.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value)));
+  r.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value / side)));
+  return r;
+}
+#undef LT_BSTAMP
 
 // copy the FFT twiddles and the filter spectrum of one root into LDS (2 x 8 KB)
 __device__ __forceinline__ void load_filter_lds(v2f *tw, v2f *spec, const DeviceTables *__restrict__ tab, int n_id_2)

@@ -45,6 +45,25 @@ template <bool kConjB> LT_HD c32 cmul(c32 a, c32 b)
   return __builtin_elementwise_fma(q, s, p); // (ax bx - ay by, ax by + ay bx)
 }
 template <bool kInv> LT_HD c32 cw(c32 w) { return kInv ? c32{w.x, -w.y} : w; } // compile-time twiddle
+// a * w for a compile-time w: both w and j w fold into constant operands, 2 packed ops
+LT_HD c32 cmulc(c32 a, c32 w)
+{
+  const c32 axx = {a.x, a.x}, ayy = {a.y, a.y}, jw = {-w.y, w.x};
+  return __builtin_elementwise_fma(axx, w, ayy * jw); // (ax wx - ay wy, ax wy + ay wx)
+}
+// Table twiddles for the full-wave transform carry w and j w side by side, so that a * w and
+// a * conj(w) are 2 packed ops each (the swaps are operand selects, not instructions).
+typedef float c32x2 __attribute__((ext_vector_type(4))); // (wx, wy, -wy, wx)
+template <bool kConjB> LT_HD c32 cmul2(c32 a, c32x2 t)
+{
+  const c32 axx = {a.x, a.x}, ayy = {a.y, a.y};
+  if (kConjB) {
+    const c32 wyx = {t.y, t.x}, wc = {t.w, t.z};            // (wy, wx), (wx, -wy)
+    return __builtin_elementwise_fma(axx, wc, ayy * wyx);   // (ax wx + ay wy, -ax wy + ay wx)
+  }
+  const c32 w = {t.x, t.y}, jw = {t.z, t.w};
+  return __builtin_elementwise_fma(axx, w, ayy * jw);       // (ax wx - ay wy, ax wy + ay wx)
+}
 
 // radix-4 butterfly, forward (W4 = -j) or inverse (W4 = +j)
 template <bool kInv> LT_HD void radix4(c32 a, c32 b, c32 c, c32 d, c32 &y0, c32 &y1, c32 &y2, c32 &y3)
@@ -72,15 +91,15 @@ template <int S, bool kInv> LT_HD void fft16(c32 *v)
   const c32 w4 = cw<kInv>(c32{0.f, -1.f});
   const c32 w6 = cw<kInv>(c32{-0.70710678118654752f, -0.70710678118654752f});
   const c32 w9 = cw<kInv>(c32{-0.92387953251128674f, 0.38268343236508977f});
-  t[4 * 1 + 1] = cmul<false>(t[4 * 1 + 1], w1);
-  t[4 * 1 + 2] = cmul<false>(t[4 * 1 + 2], w2);
-  t[4 * 1 + 3] = cmul<false>(t[4 * 1 + 3], w3);
-  t[4 * 2 + 1] = cmul<false>(t[4 * 2 + 1], w2);
-  t[4 * 2 + 2] = cmul<false>(t[4 * 2 + 2], w4);
-  t[4 * 2 + 3] = cmul<false>(t[4 * 2 + 3], w6);
-  t[4 * 3 + 1] = cmul<false>(t[4 * 3 + 1], w3);
-  t[4 * 3 + 2] = cmul<false>(t[4 * 3 + 2], w6);
-  t[4 * 3 + 3] = cmul<false>(t[4 * 3 + 3], w9);
+  t[4 * 1 + 1] = cmulc(t[4 * 1 + 1], w1);
+  t[4 * 1 + 2] = cmulc(t[4 * 1 + 2], w2);
+  t[4 * 1 + 3] = cmulc(t[4 * 1 + 3], w3);
+  t[4 * 2 + 1] = cmulc(t[4 * 2 + 1], w2);
+  t[4 * 2 + 2] = cmulc(t[4 * 2 + 2], w4);
+  t[4 * 2 + 3] = cmulc(t[4 * 2 + 3], w6);
+  t[4 * 3 + 1] = cmulc(t[4 * 3 + 1], w3);
+  t[4 * 3 + 2] = cmulc(t[4 * 3 + 2], w6);
+  t[4 * 3 + 3] = cmulc(t[4 * 3 + 3], w9);
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1)
     radix4<kInv>(t[4 * k1 + 0], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3], v[S * k1], v[S * (k1 + 4)],
@@ -113,7 +132,7 @@ template <bool kInv> LT_HD void fft32(c32 v[32])
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const c32 e = v[2 * k];
-    const c32 o = (k == 0) ? v[1] : cmul<false>(v[2 * k + 1], cw<kInv>(w[k]));
+    const c32 o = (k == 0) ? v[1] : cmulc(v[2 * k + 1], cw<kInv>(w[k]));
     lo[k] = e + o;
     hi[k] = e - o;
   }
@@ -142,6 +161,51 @@ template <bool kInv> LT_HD void fft1024_stage2(int l, c32 v[32], const c32 *e)
 #pragma unroll
   for (int m = 0; m < 32; ++m) v[m] = e[l * kRow + m];
   fft32<kInv>(v);
+}
+
+// ---- full-wave variant (bulk lag-metric kernel): 64 lanes transform one 1024-sample block, 16 values
+// per lane (1024 = 16 x 16 x 4), so a lane needs half the registers of the half-wave form and four
+// waves per SIMD fit.  Element index i = lane + 64 * reg on input AND output.
+//   stage A  radix-16 over reg:  a[k1] = sum_r x[l + 64 r] W16^(r k1),  times W1024^(l k1)
+//   exchange 1                   E1[k1][l]  ->  lane (k1, c) = 4 k1 + c reads E1[k1][c + 4 s], s = 0..15
+//   stage B  radix-16 over s:    b[t] = sum_s E1[k1][c + 4 s] W16^(s t),  times W64^(c t)
+//   exchange 2                   E2[c][k1 + 16 t]  ->  lane l reads E2[0..3][l + 64 i], i = 0..3
+//   stage C  radix-4 over c:     X[(l + 64 i) + 256 u] = sum_c E2[c][l + 64 i] W4^(c u)   (reg i + 4 u)
+// Row strides 68 (E1) and 264 (E2) keep every 32-lane half of a b64 access on 32 distinct banks.
+// E1 and E2 may be the same memory: a wave has read all of E1 before it writes E2 (program order).
+constexpr int kRowA = 68;                  // E1[16][68]
+constexpr int kRowC = 264;                 // E2[4][264]
+constexpr int kScratchW = 16 * kRowA;      // c32 entries of scratch per transform (8704 B; 4 * 264 fits too)
+// tw1[k1 * 64 + l] = W1024^(l k1) (k1 < 16, l < 64);  tw2[t * 4 + c] = W64^(c t) (t < 16, c < 4),
+// both as c32x2 entries (w, j w)
+template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const c32x2 *tw1, c32 *e)
+{
+  fft16<1, kInv>(v);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) {
+    if (k1) v[k1] = cmul2<kInv>(v[k1], tw1[k1 * 64 + l]);
+    e[k1 * kRowA + l] = v[k1];
+  }
+}
+template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32x2 *tw2, const c32 *e1, c32 *e2)
+{
+  const int k1 = l >> 2, c = l & 3;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = e1[k1 * kRowA + c + 4 * s];
+  fft16<1, kInv>(v);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    if (t) v[t] = cmul2<kInv>(v[t], tw2[t * 4 + c]);
+    e2[c * kRowC + k1 + 16 * t] = v[t];
+  }
+}
+template <bool kInv> LT_HD void fft1024w_stageC(int l, c32 v[16], const c32 *e2)
+{
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = l + 64 * i;
+    radix4<kInv>(e2[p], e2[kRowC + p], e2[2 * kRowC + p], e2[3 * kRowC + p], v[i], v[i + 4], v[i + 8], v[i + 12]);
+  }
 }
 
 } // namespace fft

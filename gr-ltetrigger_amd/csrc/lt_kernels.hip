@@ -31,14 +31,22 @@ struct ChainArgs {
   const float *metric;    // bulk + replay mode: P[root][channel][pos] from lt_metric_kernel, else null
   int64_t metric_ch_stride;   // floats between channels
   int64_t metric_root_stride; // floats between roots
+  const float *edge;          // bulk + replay mode: edge lags of the windows on the 9600-sample grid (lt_edge_kernel)
+  int64_t edge_ch_stride;
+  int64_t edge_root_stride;
   int ablate;             // diagnostics only (tools/probe.py): 1 = skip the window load
   unsigned long long *prof; // diagnostics only: per-phase shader-clock sums of chain 0 (ablate & 8)
 };
 
 // kDiag = true is the diagnostics build (tools/probe.py: ablation switches, in-kernel stamps, the
 // direct-form filter); the product launches kDiag = false, where all of that folds away.
-template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt_chain_kernel(ChainArgs a_in)
+// Workgroup shape: the fused kernel needs 512 threads (16 half-wave FFT blocks in flight); the replay
+// kernel runs serial-ish per-window code that every wave executes, so it takes ONE wave per SIMD
+// (256 threads, 38 lags each): two waves sharing a SIMD would only take turns issuing the same work.
+template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsReplay : kThreads) void lt_chain_kernel(ChainArgs a_in)
 {
+  constexpr int NT = kBulk ? kThreadsReplay : kThreads; // threads
+  constexpr int NL = kConvLen / NT;                     // lags per thread
   ChainArgs a = a_in;
   if (!kDiag) {
     a.ablate = 0;
@@ -47,7 +55,10 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
   // fused mode: window buffer (also FFT scratch), twiddles and filter spectrum; replay mode: only the
   // 2 x 128 edge samples of the window
   __shared__ v2f W[kBulk ? 256 : kWLen];
-  __shared__ float AVG[kAvgLen];
+  // replay mode: two EMA mirrors used in turn, so that a wave still reading the previous search's mirror
+  // and a wave already writing the next one never meet (no barrier between searches)
+  __shared__ float AVG_[kBulk ? 2 * kAvgLen : kAvgLen];
+  float *AVG = AVG_;
   __shared__ v2f S[kSssLen];
   __shared__ v2f RAW[kSssLen];
   __shared__ LdsTables ltab;
@@ -56,6 +67,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
   __shared__ float psr_data[kMovingAvgSz];
   __shared__ float cfo_data[kMovingAvgSz];
   __shared__ Scratch sc;
+  __shared__ BulkShared<NT> bs;
 
   const int tid = threadIdx.x;
   // blocks c, c + n_channels, c + 2 n_channels are the three roots of channel c: with n_channels a
@@ -71,18 +83,25 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
 
   // ---- load state
-  float ema[kT];
+  float ema[NL];
 #pragma unroll
-  for (int t = 0; t < kT; ++t) ema[t] = st->avg[tid * kT + t];
-  for (int i = tid; i < kMovingAvgSz; i += kThreads) {
+  for (int t = 0; t < NL; ++t) ema[t] = st->avg[kBulk ? tid + t * NT : tid * NL + t];
+  for (int i = tid; i < kMovingAvgSz; i += NT) {
     psr_data[i] = st->psr_data[i];
     cfo_data[i] = st->cfo_data[i];
   }
-  if (tid < kAvgLen - kConvLen) AVG[kConvLen + tid] = 0.f;
+  if (tid < kAvgLen - kConvLen) {
+    AVG_[kConvLen + tid] = 0.f;
+    if (kBulk) AVG_[kAvgLen + kConvLen + tid] = 0.f;
+  }
   load_lds_tables(ltab, tab, n_id_2);
   if (!kBulk) load_filter_lds(TW, SPEC, tab, n_id_2);
   const FilterLds fl = {TW, SPEC};
   const float *__restrict__ P = kBulk ? a.metric + n_id_2 * a.metric_root_stride + channel * a.metric_ch_stride : nullptr;
+  const float *__restrict__ EP = kBulk ? a.edge + n_id_2 * a.edge_root_stride + channel * a.edge_ch_stride : nullptr;
+  int grid_k = 0;   // replay mode: pos == 9600 * grid_k while the chain is on the grid, else -1
+  int buf = 0;      // replay mode: which EMA mirror / maxima set the next search writes
+  bool pf_edges = false; // replay mode: the prefetched slice carries its edge lags (window on the grid)
   int64_t pos = 0; // every run starts at sample 0 of the capture handed to it
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
@@ -92,18 +111,36 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
   float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
   int nrec = 0;
   const int call_base = st->n_calls;
-  v2f pf[kBulk ? 1 : kT]; // fused mode: next window, prefetched (19 * 512 = 9728 >= 9600 samples)
-  float pfm[kBulk ? kT : 1]; // replay mode: next window's interior metric slice
+  v2f pf[kBulk ? 1 : NL]; // fused mode: next window, prefetched (19 * 512 = 9728 >= 9600 samples)
+  float pfm[kBulk ? NL : 1]; // replay mode: next window's interior metric slice
   v2f pfe = {0.f, 0.f};      // replay mode: one of the next window's 256 edge samples (tid < 256)
   int64_t pf_pos = -1;       // stream position the prefetch belongs to, -1 = none
 #pragma unroll
-  for (int i = 0; i < (kBulk ? 1 : kT); ++i) pf[i] = v2f{0.f, 0.f};
+  for (int i = 0; i < (kBulk ? 1 : NL); ++i) pf[i] = v2f{0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < (kBulk ? kT : 1); ++i) pfm[i] = 0.f;
+  for (int i = 0; i < (kBulk ? NL : 1); ++i) pfm[i] = 0.f;
   unsigned long long prof[24] = {0};
   unsigned long long *profp = (kDiag && (a.ablate & 8) && a.prof) ? prof : nullptr;
   __syncthreads();
 
+  // replay mode: thread's 19 lags of the window at q: interior from P, edge lags from the grid table
+  // (window index k >= 0) or left alone (k < 0: the caller computes them)
+  constexpr int kTailTid0 = kHalfFrame - (NL - 1) * NT; // thread owning lag 9600 in its last slot (384)
+  auto load_slice = [&](float (&m)[kBulk ? NL : 1], int64_t q, int k) {
+    if (kDiag && (a.ablate & 1)) { // diagnostics: no HBM reads
+#pragma unroll
+      for (int i = 0; i < (kBulk ? NL : 1); ++i) m[i] = (float)((tid * 7 + i) & 15);
+      return;
+    }
+    const float *__restrict__ Pq = P + q + tid;
+#pragma unroll
+    for (int i = 1; i < NL - 1; ++i) m[i] = Pq[i * NT];
+    const float *__restrict__ Ek = EP + (int64_t)(k < 0 ? 0 : k) * 256;
+    if (tid >= kSymbolSz - 1) m[0] = Pq[0];
+    else if (k >= 0) m[0] = Ek[tid];
+    if (tid < kTailTid0) m[NL - 1] = Pq[(NL - 1) * NT];
+    else if (k >= 0 && tid < kTailTid0 + 126) m[NL - 1] = Ek[kSymbolSz - 1 + tid - kTailTid0];
+  };
   while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
     uint32_t flags = 0;
     float peak_value = 0.f;
@@ -112,55 +149,68 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
     if (!is_tracking || timer == 0) {
       timer = a.track_every;
       unsigned long long t0_ = profp ? __builtin_amdgcn_s_memtime() : 0;
-      if (kBulk) {
-        // interior lags 127..9599 = position-independent metric; edges recomputed from the samples
+      SearchResult r;
+      if constexpr (kBulk) {
+        // lag tid + 512 i.  Interior lags 127..9599 = position-independent metric P[pos + lag]; the 253
+        // edge lags come from lt_edge_kernel's table while the chain is on the 9600-sample grid and are
+        // recomputed from the window's first and last 128 samples once it has re-aligned.
+        float met[NL];
+        bool have_edges;
         if (pf_pos == pos) {
 #pragma unroll
-          for (int i = 0; i < kT; ++i) {
-            const int k = (kSymbolSz - 1) + tid + i * kThreads;
-            if (k < kHalfFrame) AVG[k] = pfm[i];
-          }
-          if (tid < 256) W[tid] = pfe;
+          for (int i = 0; i < NL; ++i) met[i] = pfm[i];
+          have_edges = pf_edges;
+          if (!have_edges && tid < 256) W[tid] = pfe; // (NT = 256: every thread carries one edge sample)
         } else {
-          for (int k = (kSymbolSz - 1) + tid; k < kHalfFrame; k += kThreads) AVG[k] = P[pos + k];
-          if (tid < 128) W[tid] = x[pos + kHalfFrame - 128 + tid]; // Z = [window tail | window head]
-          else if (tid < 256) W[tid] = x[pos - 128 + tid];
-        }
-        __syncthreads();
-        if (profp) prof[14] += __builtin_amdgcn_s_memtime() - t0_; // metric slice arrives
-        edge_lags(W, ltab.taps, AVG, tid, kThreads);
-        if (profp) prof[15] += __builtin_amdgcn_s_memtime() - t0_; // + edge lags
-        __syncthreads();
-        if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // metric load + edges
-        float met[kT];
-#pragma unroll
-        for (int t = 0; t < kT; ++t) met[t] = AVG[tid * kT + t];
-        search_ema(met, AVG, ema, sc, a.ablate, profp);
-        pf_pos = -1;
-        if (pos + 2 * kHalfFrame <= n) { // prefetch what a miss leads to
-          pf_pos = pos + kHalfFrame;
-#pragma unroll
-          for (int i = 0; i < kT; ++i) {
-            const int k = (kSymbolSz - 1) + tid + i * kThreads;
-            if (k < kHalfFrame) pfm[i] = P[pf_pos + k];
+          have_edges = grid_k >= 0;
+          load_slice(met, pos, grid_k);
+          if (!have_edges) {
+            if (tid < 128) W[tid] = x[pos + kHalfFrame - 128 + tid]; // Z = [window tail | window head]
+            else if (tid < 256) W[tid] = x[pos - 128 + tid];
           }
-          if (tid < 128) pfe = x[pf_pos + kHalfFrame - 128 + tid];
-          else if (tid < 256) pfe = x[pf_pos - 128 + tid];
         }
+        if (!have_edges) { // (block-uniform)
+          __syncthreads();
+          edge_lags(W, ltab.taps, bs.edge, bs.edge + 127, tid, NT);
+          __syncthreads();
+          if (tid < kSymbolSz - 1) met[0] = bs.edge[tid];
+          if (tid >= kTailTid0 && tid < kTailTid0 + 126) met[NL - 1] = bs.edge[kSymbolSz - 1 + tid - kTailTid0];
+        }
+        if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // metric slice (+ edges)
+        unsigned long long t1_ = profp ? __builtin_amdgcn_s_memtime() : 0;
+        AVG = AVG_ + buf * kAvgLen;
+        bulk_search_ema<NT, NL>(met, ema, AVG, bs.tmax[buf], bs.tidx[buf]);
+        // prefetch the next search's inputs: a miss leads to pos + 9600; a tracked chain that keeps its
+        // timing searches again track_every + 1 half-frames on
+        const int ahead = is_tracking ? a.track_every + 1 : 1;
+        pf_pos = pos + (int64_t)kHalfFrame * ahead;
+        if (pf_pos + kHalfFrame <= n) {
+          pf_edges = grid_k >= 0;
+          load_slice(pfm, pf_pos, pf_edges ? grid_k + ahead : -1);
+          if (!pf_edges) {
+            if (tid < 128) pfe = x[pf_pos + kHalfFrame - 128 + tid];
+            else if (tid < 256) pfe = x[pf_pos - 128 + tid];
+          }
+        } else {
+          pf_pos = -1;
+        }
+        if (profp) prof[1] += __builtin_amdgcn_s_memtime() - t1_; // EMA + mirror + prefetch issue
+        r = bulk_search_tail<NT, NL>(ema, AVG, bs.tmax[buf], bs.tidx[buf], bs.sl, profp);
+        buf ^= 1;
       } else {
         if (!(a.ablate & 1)) {
           if (pf_pos == pos) { // prefetched under the previous search's tail
 #pragma unroll
-            for (int i = 0; i < (kBulk ? 1 : kT); ++i) {
-              const int k = tid + i * kThreads;
+            for (int i = 0; i < (kBulk ? 1 : NL); ++i) {
+              const int k = tid + i * NT;
               if (k < kHalfFrame) W[kWPad + k] = pf[i];
             }
           } else {
-            for (int i = tid; i < kHalfFrame; i += kThreads) W[kWPad + i] = x[pos + i];
+            for (int i = tid; i < kHalfFrame; i += NT) W[kWPad + i] = x[pos + i];
           }
           // the zero pads around the window (the matched filter used W as scratch last time)
-          for (int i = tid; i < kWPad; i += kThreads) W[i] = v2f{0.f, 0.f};
-          for (int i = kWPad + kHalfFrame + tid; i < kWLen; i += kThreads) W[i] = v2f{0.f, 0.f};
+          for (int i = tid; i < kWPad; i += NT) W[i] = v2f{0.f, 0.f};
+          for (int i = kWPad + kHalfFrame + tid; i < kWLen; i += NT) W[i] = v2f{0.f, 0.f};
         }
         __syncthreads();
         if (profp) prof[6] += __builtin_amdgcn_s_memtime() - t0_; // window load
@@ -171,13 +221,13 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
         if (!(a.ablate & 1) && pos + 2 * kHalfFrame <= n) {
           pf_pos = pos + kHalfFrame;
 #pragma unroll
-          for (int i = 0; i < (kBulk ? 1 : kT); ++i) {
-            const int k = tid + i * kThreads;
+          for (int i = 0; i < (kBulk ? 1 : NL); ++i) {
+            const int k = tid + i * NT;
             if (k < kHalfFrame) pf[i] = x[pf_pos + k];
           }
         }
+        r = search_tail(AVG, sc, a.ablate, profp);
       }
-      const SearchResult r = search_tail(AVG, sc, a.ablate, profp);
       if (profp) prof[7] += 1;
       peak_pos = r.peak_pos;
       psr = r.psr;
@@ -198,7 +248,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
         if (!is_tracking && score == a.track_after) {
           is_tracking = 1;
 #pragma unroll
-          for (int t = 0; t < kT; ++t) ema[t] = 0.f; // srslte_pss_reset
+          for (int t = 0; t < NL; ++t) ema[t] = 0.f; // srslte_pss_reset
         }
       }
       flags |= LT_F_OVER;
@@ -207,7 +257,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
       timer = 0;
       is_tracking = 0;
 #pragma unroll
-      for (int t = 0; t < kT; ++t) ema[t] = 0.f;
+      for (int t = 0; t < NL; ++t) ema[t] = 0.f;
       psr_i = 0;
       cfo_i = 0;
       tracking_lost = 1;
@@ -241,7 +291,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
         // stage half-frame samples [480, 960) once (coalesced); everything below reads LDS
         // (by waves 1..7: wave 0 arrives last from the previous emission's m0/m1 search and finds
         // the samples already in LDS)
-        for (int i = tid - 64; i >= 0 && i < kSssLen; i += kThreads - 64) RAW[i] = ld_iq(x, n, hf0 + kSssBase + i);
+        for (int i = tid - 64; i >= 0 && i < kSssLen; i += NT - 64) RAW[i] = ld_iq(x, n, hf0 + kSssBase + i);
         __syncthreads();
         LT_TSTAMP(8) // stage raw samples
         // srslte_pss_cfo_compute on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring
@@ -268,9 +318,9 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
         // srslte_cfo_correct(out, out, -mean_cfo()/symbol_sz), lib/pss_impl.cc:204
         const float freq = -mean_cfo / (float)kSymbolSz;
         const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-        if (tid < kSssLen) S[tid] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + tid, RAW[tid]);
+        for (int i = tid; i < kSssLen; i += NT) S[i] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + i, RAW[i]);
         if (out)
-          for (int i = tid; i < kHalfFrame; i += kThreads)
+          for (int i = tid; i < kHalfFrame; i += NT)
             out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
         __syncthreads();
         LT_TSTAMP(11) // rotation
@@ -300,7 +350,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
         m_norm_avg = 0.f;
         m_ext_avg = 0.f;
         if (out)
-          for (int i = tid; i < kHalfFrame; i += kThreads) out[i] = ld_iq(x, n, hf0 + i);
+          for (int i = tid; i < kHalfFrame; i += NT) out[i] = ld_iq(x, n, hf0 + i);
       }
       n_emits++;
     } else {
@@ -319,6 +369,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
       recs[nrec] = r;
     }
     nrec++;
+    if (kBulk) grid_k = (grid_k >= 0 && next_pos == pos + kHalfFrame) ? grid_k + 1 : -1;
     pos = next_pos;
   }
 
@@ -327,8 +378,8 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kThreads) void lt
   // ---- store state
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < kT; ++t) st->avg[tid * kT + t] = ema[t];
-  for (int i = tid; i < kMovingAvgSz; i += kThreads) {
+  for (int t = 0; t < NL; ++t) st->avg[kBulk ? tid + t * NT : tid * NL + t] = ema[t];
+  for (int i = tid; i < kMovingAvgSz; i += NT) {
     st->psr_data[i] = psr_data[i];
     st->cfo_data[i] = cfo_data[i];
   }
@@ -483,9 +534,9 @@ __global__ __launch_bounds__(256) void lt_decim_kernel(const v2f *__restrict__ x
 // ---------------------------------------------------------------- bulk lag metric (bulk + replay mode)
 // P[root][channel][p] = | sum_m h_root[m] x[channel][p - m] |^2 for every sample position p (x[<0] = 0):
 // the position-independent part of srslte_pss_find_pss's convolution, for all three roots from ONE
-// forward FFT per 1024-sample overlap-save block (897 new positions per block).  One half-wave per
-// block, 16 blocks per workgroup; inputs come straight from HBM (32 x 256-byte rows per block),
-// outputs go back as 3 x 897 floats.  Algorithmic bytes: 8 B read + 12 B written per sample.
+// forward FFT per 1024-sample overlap-save block (897 new positions per block).  One wave per block
+// (csrc/lt_fft.h, full-wave form: 16 values per lane), 8 blocks per workgroup; inputs come straight
+// from HBM (16 x 512-byte rows per block), outputs go back as 3 x 897 floats.  Algorithmic bytes: 8 B read + 12 B written per sample.
 struct MetricArgs {
   const v2f *iq;   // [n_channels][ch_stride]
   int64_t n_samples;
@@ -498,46 +549,210 @@ struct MetricArgs {
   const DeviceTables *tab;
 };
 
-constexpr int kMetricThreads = 256;                 // 8 half-waves = 8 blocks per workgroup, two workgroups per CU
-constexpr int kMetricBlocks = kMetricThreads / 32;
+#define LT_SB __builtin_amdgcn_sched_barrier(0)
+constexpr int kMetricWaves = 12;                  // one 1024-sample block per wave at a time, three waves per SIMD
+constexpr int kMetricThreads = 64 * kMetricWaves; // ONE workgroup per CU: the tables below are shared by all 12 waves
 
-template <int kAbl> __global__ __launch_bounds__(kMetricThreads, 2) void lt_metric_kernel(MetricArgs a)
+// kAbl: diagnostics only (LT_METRIC_ABL): 1 = no stores, 2 = no loads
+template <int kAbl> __global__ __launch_bounds__(kMetricThreads) void lt_metric_kernel(MetricArgs a)
 {
-  __shared__ v2f E[kMetricBlocks * fft::kScratch]; // one exchange area per half-wave (67.6 KB)
-  __shared__ v2f TW[fft::kN];
-  const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
-  for (int i = tid; i < fft::kN; i += kMetricThreads) TW[i] = v2f{a.tab->fft_tw[i].re, a.tab->fft_tw[i].im};
-  __syncthreads();
-  const int64_t g = (int64_t)blockIdx.x * kMetricBlocks + hw; // global block index
-  const int64_t total = (int64_t)a.n_channels * a.blocks_per_channel;
-  if (g >= total) return; // whole half-wave leaves together; no barrier follows
-  const int ch = (int)(g / a.blocks_per_channel);
-  const int64_t j = g % a.blocks_per_channel;
-  const v2f *__restrict__ x = a.iq + (int64_t)ch * a.ch_stride;
-  const int64_t base = j * kBlkValid - (kSymbolSz - 1); // first input sample of the block
-  fft::c32 xf[32], v[32];
+  __shared__ v2f E[kMetricWaves * fft::kScratchW]; // one exchange area per wave (12 x 8.5 KB)
+  __shared__ fft::c32x2 TW1[16 * 64];              // 16 KB
+  __shared__ fft::c32x2 TW2[16 * 4];               // 1 KB
+  __shared__ v2f SPEC[3 * fft::kN];                // 24 KB: the three filter spectra / 1024
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 16 * 64; i += kMetricThreads) TW1[i] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw1[i]);
+  if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw2[tid]);
+  for (int i = tid; i < 3 * fft::kN; i += kMetricThreads) {
+    const cf32 h = a.tab->pss_spec[i >> 10][i & 1023];
+    SPEC[i] = v2f{h.re, h.im};
+  }
+  __syncthreads(); // the only barrier: from here on every wave works through its own blocks alone
+  const uint32_t total = (uint32_t)a.n_channels * (uint32_t)a.blocks_per_channel;
+  const uint32_t stride = gridDim.x * kMetricWaves;
+  uint32_t g = blockIdx.x * kMetricWaves + w; // block index: channel-major, consecutive waves = consecutive blocks
+  if (g >= total) return;
+  fft::c32 *e = E + w * fft::kScratchW;
+  fft::c32 xf[16], v[16];
+
+  // input samples base .. base+1023 of block g (first 127 = overlap with the previous block)
+  auto load_block = [&](uint32_t gb) {
+    const uint32_t ch = gb / (uint32_t)a.blocks_per_channel;
+    const uint32_t jb = gb - ch * (uint32_t)a.blocks_per_channel;
+    const v2f *__restrict__ x = a.iq + (int64_t)ch * a.ch_stride;
+    const int64_t base = (int64_t)jb * kBlkValid - (kSymbolSz - 1);
+    if (kAbl & 2) {
 #pragma unroll
-  for (int r = 0; r < 32; ++r) xf[r] = (kAbl & 2) ? fft::c32{(float)(l + r), (float)g} : ld_iq(x, a.n_samples, base + l + 32 * r);
-  fft::c32 *e = E + hw * fft::kScratch;
-  fft::fft1024_stage1<false>(l, xf, TW, e);
-  fft::fft1024_stage2<false>(l, xf, e);
-#pragma unroll 1
-  for (int root = 0; root < ((kAbl & 4) ? 1 : 3); ++root) {
-    const cf32 *__restrict__ spec = a.tab->pss_spec[root];
+      for (int r = 0; r < 16; ++r) xf[r] = fft::c32{(float)(l + r), (float)gb};
+    } else if (base >= 0 && base + fft::kN <= a.n_samples) { // interior block: no bounds checks
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      const cf32 h = spec[r * 32 + l];
-      v[r] = fft::cmul<false>(xf[r], fft::c32{h.re, h.im});
+      for (int r = 0; r < 16; ++r) xf[r] = x[base + l + 64 * r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xf[r] = ld_iq(x, a.n_samples, base + l + 64 * r);
     }
-    fft::fft1024_stage1<true>(l, v, TW, e);
-    fft::fft1024_stage2<true>(l, v, e);
-    float *__restrict__ out = a.metric + root * a.metric_root_stride + ch * a.metric_ch_stride;
+  };
+  // |v|^2 of the 897 valid positions of block gb, root `root`
+  auto store_block = [&](uint32_t gb, int root) {
+    const uint32_t ch = gb / (uint32_t)a.blocks_per_channel;
+    const uint32_t jb = gb - ch * (uint32_t)a.blocks_per_channel;
+    const int64_t base = (int64_t)jb * kBlkValid - (kSymbolSz - 1);
+    float *__restrict__ out = a.metric + root * a.metric_root_stride + (int64_t)ch * a.metric_ch_stride + base;
+    if (kAbl & 1) {
+      float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      const int i = l + 32 * r;
-      const int64_t p = base + i;
-      if (i >= kSymbolSz - 1 && p < a.n_samples && (!(kAbl & 1) || v[r].x == 1234.5f))
-        out[p] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+      for (int r = 1; r < 16; ++r) s += v[r].x + v[r].y;
+      if (s == 1234.5f) out[l + 64] = s;
+    } else if (base + fft::kN <= a.n_samples) {
+      if (l == 63) out[127] = __fadd_rn(__fmul_rn(v[1].x, v[1].x), __fmul_rn(v[1].y, v[1].y)); // reg 1 = positions 64..127
+#pragma unroll
+      for (int r = 2; r < 16; ++r) out[l + 64 * r] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+    } else {
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        const int i = l + 64 * r;
+        if (i >= kSymbolSz - 1 && base + i < a.n_samples)
+          out[i] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+      }
+    }
+  };
+  auto inverse = [&]() {
+    LT_SB;
+    fft::fft1024w_stageA<true>(l, v, TW1, e);
+    LT_SB;
+    fft::fft1024w_stageB<true>(l, v, TW2, e, e);
+    LT_SB;
+    fft::fft1024w_stageC<true>(l, v, e);
+    LT_SB;
+  };
+
+  load_block(g);
+  for (;;) {
+    fft::fft1024w_stageA<false>(l, xf, TW1, e);
+    LT_SB;
+    fft::fft1024w_stageB<false>(l, xf, TW2, e, e);
+    LT_SB;
+    fft::fft1024w_stageC<false>(l, xf, e);
+    LT_SB;
+#pragma unroll
+    for (int root = 0; root < 2; ++root) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fft::cmul<false>(xf[r], SPEC[root * fft::kN + r * 64 + l]);
+      inverse();
+      store_block(g, root);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fft::cmul<false>(xf[r], SPEC[2 * fft::kN + r * 64 + l]);
+    LT_SB;
+    // the spectrum of this block is no longer needed: fetch the next block under the last transform
+    const uint32_t g_next = g + stride;
+    const bool more = g_next < total;
+    if (more) load_block(g_next);
+    inverse();
+    store_block(g, 2);
+    if (!more) break;
+    g = g_next;
+  }
+}
+
+// ---------------------------------------------------------------- window-edge lags on the 9600-sample grid
+// A window's first 127 and last 126 lags see its zero padding, so they are not in P.  A chain that has
+// not re-aligned yet (every chain that never fires, i.e. almost all of them) searches the windows
+// [9600 k, 9600 k + 9600) of the capture: their edge lags are computed here for all three roots, chip
+// wide, and the replay kernel picks them up with its metric prefetch (chains off the grid compute their
+// own, device function edge_lags).
+//   edge[root][channel][k][0..126]   = | sum_{m<=j} h[m] x[9600 k + j - m] |^2          (lag j)
+//   edge[root][channel][k][127+j]    = | sum_{m>j}  h[m] x[9600 k + 9600 + j - m] |^2   (lag 9600 + j, j < 126)
+// One lane per (channel, window), 64 consecutive ones per wave; a wave takes a tile of 8 units j0..j0+7
+// (j0 = 8 * tile) through all 128 taps in 16 steps of 8 taps.  With j0 wave-uniform the split of a step's
+// products into head and tail sums is known at compile time (steps before tap j0: all head; the step
+// at tap j0: a fixed staircase; steps after it: all tail), so the work is the exact triangle: no
+// predicates, no zero padding.  Taps are wave-uniform (scalar loads), samples come per lane from L1/L2.
+struct EdgeArgs {
+  const v2f *iq;
+  int64_t ch_stride;
+  int n_channels;
+  int n_windows;       // windows per channel on the grid: floor(n_samples / 9600)
+  float *edge;         // [3][n_channels][edge_win_stride / 256][256]
+  int64_t edge_ch_stride;   // floats between channels
+  int64_t edge_root_stride; // floats between roots
+  const DeviceTables *tab;
+};
+
+// kMode 0: all 64 products of the step go to the head sums, 2: to the tail sums, 1: tap j0 + d feeds
+// the head sum of unit u when u >= d and its tail sum otherwise.
+template <int kMode>
+__device__ __forceinline__ void edge_step(const v2f *__restrict__ zp, const cf32 *__restrict__ h0, const cf32 *__restrict__ h1,
+                                          const cf32 *__restrict__ h2, int m0, float (&H)[3][8][2], float (&T)[3][8][2])
+{
+  // samples zs[i] = Z[z0 - 7 + i], i = 0..14, where unit u / tap m0 + t reads Z[z0 + u - t]
+  v2f zs[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) zs[i] = zp[i - 7];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const cf32 hh[3] = {h0[m0 + t], h1[m0 + t], h2[m0 + t]};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const v2f z = zs[u - t + 7];
+      const bool head = kMode == 0 || (kMode == 1 && u >= t);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float &re = head ? H[r][u][0] : T[r][u][0];
+        float &im = head ? H[r][u][1] : T[r][u][1];
+        re = fmaf(hh[r].re, z.x, re);
+        re = fmaf(-hh[r].im, z.y, re);
+        im = fmaf(hh[r].re, z.y, im);
+        im = fmaf(hh[r].im, z.x, im);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lt_edge_kernel(EdgeArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = __builtin_amdgcn_readfirstlane(wave & 15); // units 8 tile .. 8 tile + 7
+  const int group = __builtin_amdgcn_readfirstlane(wave >> 4); // 64 (channel, window) pairs
+  const int total = a.n_channels * a.n_windows;
+  int pair = group * 64 + lane;
+  const bool live = pair < total;
+  if (!live) pair = total - 1; // keep the lane busy on valid addresses, drop its stores
+  const int ch = pair / a.n_windows, k = pair - ch * a.n_windows;
+  const v2f *__restrict__ x = a.iq + (int64_t)ch * a.ch_stride + (int64_t)k * kHalfFrame;
+  // Z = [ x[9472 .. 9600) | x[0 .. 128) ] of the window: Z[i >= 128] = x[i - 128], Z[i < 128] = x[9472 + i]
+  const v2f *__restrict__ zh = x - 128;               // head half, indexed by Z index
+  const v2f *__restrict__ zt = x + (kHalfFrame - 128); // tail half, indexed by Z index
+  const cf32 *__restrict__ h0 = a.tab->pss_taps[0];
+  const cf32 *__restrict__ h1 = a.tab->pss_taps[1];
+  const cf32 *__restrict__ h2 = a.tab->pss_taps[2];
+  const int j0 = 8 * tile;
+  float H[3][8][2], T[3][8][2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) H[r][u][0] = H[r][u][1] = T[r][u][0] = T[r][u][1] = 0.f;
+  // unit j0 + u, tap m reads Z[128 + j0 + u - m]
+  for (int m0 = 0; m0 < j0; m0 += 8) edge_step<0>(zh + (128 + j0 - m0), h0, h1, h2, m0, H, T);
+  { // taps j0 .. j0 + 7: Z[128 + u - d] with d = m - j0: head half iff u >= d
+    v2f zs[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) zs[i] = (i >= 7) ? zh[128 + i - 7] : zt[128 + i - 7];
+    // (the generic step reads one pointer; give it a private copy instead)
+    edge_step<1>(zs + 7, h0, h1, h2, j0, H, T);
+  }
+  for (int m0 = j0 + 8; m0 < 128; m0 += 8) edge_step<2>(zt + (128 + j0 - m0), h0, h1, h2, m0, H, T);
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float *__restrict__ out = a.edge + r * a.edge_root_stride + (int64_t)ch * a.edge_ch_stride + (int64_t)k * 256;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u;
+      if (j < 127) out[j] = __fadd_rn(__fmul_rn(H[r][u][0], H[r][u][0]), __fmul_rn(H[r][u][1], H[r][u][1]));
+      if (j < 126) out[127 + j] = __fadd_rn(__fmul_rn(T[r][u][0], T[r][u][0]), __fmul_rn(T[r][u][1], T[r][u][1]));
     }
   }
 }
@@ -571,6 +786,9 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
   a.metric = L.metric;
   a.metric_ch_stride = L.metric_ch_stride;
   a.metric_root_stride = L.metric_root_stride;
+  a.edge = L.edge;
+  a.edge_ch_stride = L.edge_ch_stride;
+  a.edge_root_stride = L.edge_root_stride;
   if (L.metric) {
     MetricArgs m;
     m.iq = a.iq;
@@ -583,20 +801,38 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
     m.metric_root_stride = L.metric_root_stride;
     m.tab = L.tab;
     const int64_t total = (int64_t)m.n_channels * m.blocks_per_channel;
-    if (total > 0) {
-      const unsigned grid = (unsigned)((total + kMetricBlocks - 1) / kMetricBlocks);
-      static const int abl = getenv("LT_METRIC_ABL") ? atoi(getenv("LT_METRIC_ABL")) : 0;
+    if (total > 0 && total < (int64_t)1 << 31) {
+      // persistent: one workgroup per CU (its LDS footprint allows no second one), blocks strided over all waves
+      const int64_t need = (total + kMetricWaves - 1) / kMetricWaves;
+      const unsigned grid = (unsigned)(need < L.n_cus ? need : L.n_cus);
+      static const int abl = getenv("LT_METRIC_ABL") ? atoi(getenv("LT_METRIC_ABL")) : 0; // diagnostics only
       switch (abl) {
       case 1: hipLaunchKernelGGL(lt_metric_kernel<1>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
       case 2: hipLaunchKernelGGL(lt_metric_kernel<2>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
       case 3: hipLaunchKernelGGL(lt_metric_kernel<3>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
-      case 4: hipLaunchKernelGGL(lt_metric_kernel<4>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
-      case 7: hipLaunchKernelGGL(lt_metric_kernel<7>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
       default: hipLaunchKernelGGL(lt_metric_kernel<0>, dim3(grid), dim3(kMetricThreads), 0, stream, m);
       }
+    } else if (total > 0) {
+      return hipErrorInvalidValue;
     }
-    if (L.ablate) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
-    else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
+    {
+      EdgeArgs e;
+      e.iq = a.iq;
+      e.ch_stride = L.ch_stride;
+      e.n_channels = L.n_channels;
+      e.n_windows = (int)(L.n_samples / kHalfFrame);
+      e.edge = L.edge;
+      e.edge_ch_stride = L.edge_ch_stride;
+      e.edge_root_stride = L.edge_root_stride;
+      e.tab = L.tab;
+      const int64_t pairs = (int64_t)e.n_channels * e.n_windows;
+      if (pairs > 0) {
+        const int64_t waves = ((pairs + 63) / 64) * 16;
+        hipLaunchKernelGGL(lt_edge_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, e);
+      }
+    }
+    if (L.ablate) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
+    else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
   } else if (L.ablate) {
     a.metric = nullptr;
     hipLaunchKernelGGL((lt_chain_kernel<true, false>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);

@@ -28,6 +28,10 @@ struct ChainLaunch {
   float *metric = nullptr;        // device, [3][n_channels][metric_ch_stride]: bulk + replay mode when set
   int64_t metric_ch_stride = 0;
   int64_t metric_root_stride = 0;
+  float *edge = nullptr;          // device, [3][n_channels][max_windows][256]: grid edge lags (bulk + replay mode)
+  int64_t edge_ch_stride = 0;
+  int64_t edge_root_stride = 0;
+  int n_cus = 256;      // compute units of the device (grid of the persistent metric kernel)
   int ablate = 0;       // diagnostics only
   void *prof = nullptr; // diagnostics only: 8 x uint64 on the device
 };

@@ -60,6 +60,14 @@ void m_sequence(const int taps[], int ntaps, float out[31])
   for (int i = 0; i < 31; ++i) out[i] = (float)(1 - 2 * x[i]);
 }
 
+void pair_entry(float e[4], float re, float im) // (w, j w)
+{
+  e[0] = re;
+  e[1] = im;
+  e[2] = -im;
+  e[3] = re;
+}
+
 double bessel_i0(double x)
 {
   double sum = 1, u = 1;
@@ -99,6 +107,16 @@ void build_device_tables(DeviceTables *t)
       t->fft_tw[reg * 32 + l].re = (float)std::cos(ph);
       t->fft_tw[reg * 32 + l].im = (float)std::sin(ph);
     }
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int l = 0; l < 64; ++l) {
+      const double ph = -2.0 * kPi * (double)(l * k1) / 1024.0;
+      pair_entry(t->fft_tw1[k1 * 64 + l], (float)std::cos(ph), (float)std::sin(ph));
+    }
+  for (int tt = 0; tt < 16; ++tt)
+    for (int c = 0; c < 4; ++c) {
+      const double ph = -2.0 * kPi * (double)(c * tt) / 64.0;
+      pair_entry(t->fft_tw2[tt * 4 + c], (float)std::cos(ph), (float)std::sin(ph));
+    }
   for (int r = 0; r < 3; ++r)
     for (int k = 0; k < 1024; ++k) {
       double sr = 0.0, si = 0.0;
@@ -111,6 +129,7 @@ void build_device_tables(DeviceTables *t)
       }
       t->pss_spec[r][k].re = (float)(sr / 1024.0);
       t->pss_spec[r][k].im = (float)(si / 1024.0);
+      pair_entry(t->pss_spec2[r][k], t->pss_spec[r][k].re, t->pss_spec[r][k].im);
     }
 
   float s[31], c[31], z[31];

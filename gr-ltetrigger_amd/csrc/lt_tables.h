@@ -35,6 +35,11 @@ struct DeviceTables {
   // (element k = lane + 32 reg is what lane `lane` holds in register `reg`)
   cf32 fft_tw[32 * 32];
   cf32 pss_spec[3][1024];
+  // full-wave FFT of the bulk lag-metric kernel: W1024^(l k1) as [k1][l] (16 x 64), W64^(c t) as
+  // [t][c] (16 x 4) and the filter spectra / 1024, every entry as the pair (w, j w) = (re, im, -im, re)
+  float fft_tw1[16 * 64][4];
+  float fft_tw2[16 * 4][4];
+  float pss_spec2[3][1024][4];
 };
 
 void build_device_tables(DeviceTables *t);

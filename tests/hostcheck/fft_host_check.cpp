@@ -24,7 +24,24 @@ template <bool kInv> static void transform(const std::vector<c32> &x, std::vecto
     for (int r = 0; r < 32; ++r) X[l + 32 * r] = regs[l][r];
 }
 
-int main()
+// full-wave variant: 64 lanes x 16 values, two exchanges
+template <bool kInv> static void transform_w(const std::vector<c32> &x, std::vector<c32> &X, const std::vector<c32x2> &tw1,
+                                             const std::vector<c32x2> &tw2)
+{
+  std::vector<c32> e1(kScratchW), e2(kScratchW); // the device aliases them; lane-serial emulation cannot
+  static c32 regs[64][16];
+  for (int l = 0; l < 64; ++l) {
+    for (int r = 0; r < 16; ++r) regs[l][r] = x[l + 64 * r];
+    fft1024w_stageA<kInv>(l, regs[l], tw1.data(), e1.data());
+  }
+  for (int l = 0; l < 64; ++l) fft1024w_stageB<kInv>(l, regs[l], tw2.data(), e1.data(), e2.data());
+  for (int l = 0; l < 64; ++l) fft1024w_stageC<kInv>(l, regs[l], e2.data());
+  X.assign(kN, c32{0, 0});
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 16; ++r) X[l + 64 * r] = regs[l][r];
+}
+
+int main(int argc, char **)
 {
   std::vector<c32> x(kN), tw(32 * 32);
   if (fread(x.data(), sizeof(c32), kN, stdin) != (size_t)kN) return 1;
@@ -34,6 +51,24 @@ int main()
       tw[r * 32 + l] = c32{(float)cos(ph), (float)sin(ph)};
     }
   std::vector<c32> X, Y;
+  if (argc > 1) { // any argument: check the full-wave variant instead
+    std::vector<c32x2> tw1(16 * 64), tw2(16 * 4);
+    for (int k1 = 0; k1 < 16; ++k1)
+      for (int l = 0; l < 64; ++l) {
+        const double ph = -2.0 * M_PI * (double)(l * k1) / 1024.0;
+        tw1[k1 * 64 + l] = c32x2{(float)cos(ph), (float)sin(ph), -(float)sin(ph), (float)cos(ph)};
+      }
+    for (int t = 0; t < 16; ++t)
+      for (int c = 0; c < 4; ++c) {
+        const double ph = -2.0 * M_PI * (double)(c * t) / 64.0;
+        tw2[t * 4 + c] = c32x2{(float)cos(ph), (float)sin(ph), -(float)sin(ph), (float)cos(ph)};
+      }
+    transform_w<false>(x, X, tw1, tw2);
+    fwrite(X.data(), sizeof(c32), kN, stdout);
+    transform_w<true>(X, Y, tw1, tw2);
+    fwrite(Y.data(), sizeof(c32), kN, stdout);
+    return 0;
+  }
   transform<false>(x, X, tw);
   fwrite(X.data(), sizeof(c32), kN, stdout);
   transform<true>(X, Y, tw); // unnormalised inverse of the forward result = 1024 * x

@@ -13,7 +13,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang (vector extensions)")
-def test_half_wave_fft_matches_numpy(tmp_path):
+@pytest.mark.parametrize("variant", ["half_wave", "full_wave"])
+def test_lane_level_fft_matches_numpy(tmp_path, variant):
     exe = str(tmp_path / "fft_host_check")
     src = os.path.join(ROOT, "tests", "hostcheck", "fft_host_check.cpp")
     subprocess.check_call([CLANG, "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, src])
@@ -23,7 +24,8 @@ def test_half_wave_fft_matches_numpy(tmp_path):
         if trial == 2:
             x[:] = 0
             x[5] = 1
-        out = subprocess.run([exe], input=x.tobytes(), capture_output=True, check=True).stdout
+        cmd = [exe] + (["w"] if variant == "full_wave" else [])
+        out = subprocess.run(cmd, input=x.tobytes(), capture_output=True, check=True).stdout
         r = np.frombuffer(out, dtype=np.complex64)
         fwd, inv = r[:1024], r[1024:]
         ref = np.fft.fft(x.astype(np.complex128))
