@@ -710,8 +710,18 @@ __device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 // ulp and below 2^53 of them, i.e. exactly representable in double -- the sequential sum rounds
 // nowhere, so any association gives the same bits and an xor butterfly over the wave is used.
 // Otherwise the sum runs strictly in index order through v_readlane.
+// `n_new` entries starting at ring index `new_idx` (wrapping) are taken from new_vals[0..n_new) instead of
+// the ring: entries that are being written by this call and, in the batched tracked path, by the calls
+// before it in the batch.
+__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
+                                                 uint32_t n_new, unsigned long long *slow_count = nullptr);
 __device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val,
                                                  unsigned long long *slow_count = nullptr)
+{
+  return moving_avg_wave(ring, npts, new_idx, &new_val, 1u, slow_count);
+}
+__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
+                                                 uint32_t n_new, unsigned long long *slow_count)
 {
   if (!npts) return 0.0f;
   if (npts > (uint32_t)kMovingAvgSz) npts = kMovingAvgSz;
@@ -722,7 +732,8 @@ __device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npt
   for (int k = 0; k < 4; ++k) {
     const uint32_t i = lane + 64 * k;
     float f = (i < (uint32_t)kMovingAvgSz) ? ring[i] : 0.f;
-    if (i == new_idx) f = new_val;
+    const uint32_t d = i >= new_idx ? i - new_idx : i + (uint32_t)kMovingAvgSz - new_idx; // distance past new_idx, wrapping
+    if (i < (uint32_t)kMovingAvgSz && d < n_new) f = new_vals[d];
     v[k] = (i < npts) ? f : 0.f; // x + 0.0 leaves the running sum unchanged
     const uint32_t bits = __float_as_uint(v[k]) & 0x7fffffffu;
     const uint32_t e = bits >> 23;
@@ -780,7 +791,27 @@ __device__ __forceinline__ v2f cfo_rotate(const cf32 *__restrict__ tab, float ph
 // in: samples such that in[peak_pos - 480 ...] is readable; `base` = index of sample (peak_pos-480).
 // Lane (hyp, sym, l) = lanes 0..23 sums every 4th term; returns LT_CP_NORM / LT_CP_EXT and updates
 // the two EMAs (wave-uniform).
+struct CpMetrics {
+  float m[2]; // M_norm, M_ext of this half-frame (already the per-hypothesis ratios)
+  float r[2]; // R_norm, R_ext (tie break)
+};
+__device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480);
+// EMA update and decision of srslte_sync_detect_cp from one half-frame's metrics
+__device__ __forceinline__ int cp_decide(const CpMetrics &c, float &m_norm_avg, float &m_ext_avg)
+{
+  const float alpha = 0.1f;
+  m_norm_avg = __fadd_rn(__fmul_rn(alpha, c.m[0] / 3.0f), __fmul_rn(1.0f - alpha, m_norm_avg));
+  m_ext_avg = __fadd_rn(__fmul_rn(alpha, c.m[1] / 3.0f), __fmul_rn(1.0f - alpha, m_ext_avg));
+  if (m_norm_avg > m_ext_avg) return LT_CP_NORM;
+  if (m_norm_avg < m_ext_avg) return LT_CP_EXT;
+  return (c.r[0] > c.r[1]) ? LT_CP_NORM : LT_CP_EXT;
+}
 __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_avg, float &m_ext_avg)
+{
+  const CpMetrics c = cp_metrics_wave(win480);
+  return cp_decide(c, m_norm_avg, m_ext_avg);
+}
+__device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480)
 {
   const int lane = threadIdx.x & 63;
   float pr = 0.f, pp = 0.f;
@@ -820,12 +851,10 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
     R[hyp] = r;
     M[hyp] = (c > 0.f) ? r / c : 0.f;
   }
-  const float alpha = 0.1f;
-  m_norm_avg = __fadd_rn(__fmul_rn(alpha, M[0] / 3.0f), __fmul_rn(1.0f - alpha, m_norm_avg));
-  m_ext_avg = __fadd_rn(__fmul_rn(alpha, M[1] / 3.0f), __fmul_rn(1.0f - alpha, m_ext_avg));
-  if (m_norm_avg > m_ext_avg) return LT_CP_NORM;
-  if (m_norm_avg < m_ext_avg) return LT_CP_EXT;
-  return (R[0] > R[1]) ? LT_CP_NORM : LT_CP_EXT;
+  CpMetrics out;
+  out.m[0] = M[0]; out.m[1] = M[1];
+  out.r[0] = R[0]; out.r[1] = R[1];
+  return out;
 }
 
 // 128-point forward FFT of the SSS symbol on one wave: iterative radix-2 decimation in time with the
@@ -980,15 +1009,29 @@ struct SssResult {
 
 // srslte_sss_m0m1_partial after the FFT (bins in sc.Y): two lanes per shift correlate against the 31
 // shifts of s~.  Wave-uniform result.
-__device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_, SssResult &r)
+__device__ __forceinline__ void sss_m0m1_wave(const v2f *Y, const LdsTables &lt_, SssResult &r)
 {
   const int lane = threadIdx.x & 63;
   const int m = lane & 31, half = lane >> 5;
   const uint32_t s_rot = rot31(lt_.s_mask, m < 31 ? m : 0);
-  float corr = sss_corr(sc.Y, 0, s_rot ^ lt_.c0_mask, half);
+  float corr = sss_corr(Y, 0, s_rot ^ lt_.c0_mask, half);
   r.m0 = first_max31_wave(corr, &r.m0_value);
-  corr = sss_corr(sc.Y, 1, s_rot ^ lt_.c1_mask ^ rot31(lt_.z_mask, r.m0 % 8), half);
+  corr = sss_corr(Y, 1, s_rot ^ lt_.c1_mask ^ rot31(lt_.z_mask, r.m0 % 8), half);
   r.m1 = first_max31_wave(corr, &r.m1_value);
+}
+__device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_, SssResult &r) { sss_m0m1_wave(sc.Y, lt_, r); }
+
+// sss_impl::work after the CP decision: FFT-128 of the SSS symbol, m0/m1 search, N_id_1 (one wave,
+// Y = 62 bins of LDS scratch owned by that wave)
+__device__ __forceinline__ void sss_after_cp_wave(const v2f *S, int cp, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
+                                                  v2f *Y, SssResult &r)
+{
+  r.cp = cp;
+  const int cp_len = (cp == LT_CP_NORM) ? 9 : 32;                   // srslte_sync_set_cp
+  const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len - kSssBase; // lib/sss_impl.cc:110
+  sss_fft128_wave(S + sss_idx, lt_.tw128, Y);
+  sss_m0m1_wave(Y, lt_, r);
+  r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
 }
 
 // sss_impl::work body after the tag check (lib/sss_impl.cc:102-150) on S = corrected half-frame

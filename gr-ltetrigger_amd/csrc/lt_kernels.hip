@@ -68,6 +68,14 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   __shared__ float cfo_data[kMovingAvgSz];
   __shared__ Scratch sc;
   __shared__ BulkShared<NT> bs;
+  // replay mode, batched tracked emits: one half-frame per wave
+  constexpr int NW = NT / 64;
+  __shared__ v2f RAWb[kBulk ? NW : 1][kBulk ? kSssLen : 1];
+  __shared__ v2f Sb[kBulk ? NW : 1][kBulk ? kSssLen : 1];
+  __shared__ v2f Yb[kBulk ? NW : 1][kBulk ? 62 : 1];
+  __shared__ float batch_cfo[NW];
+  __shared__ CpMetrics batch_cp[NW];
+  __shared__ float batch_avg[2];
 
   const int tid = threadIdx.x;
   // blocks c, c + n_channels, c + 2 n_channels are the three roots of channel c: with n_channels a
@@ -142,6 +150,105 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
     else if (k >= 0 && tid < kTailTid0 + 126) m[NL - 1] = Ek[kSymbolSz - 1 + tid - kTailTid0];
   };
   while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
+    if constexpr (kBulk) {
+      // ---- tracked chain between two searches (lib/pss_impl.cc:163-214 with timer > 0): the next
+      // `timer` calls neither search nor change the score; each emits the half-frame at its input
+      // position (peak_pos is 960 since the emit of the last search) and runs the SSS stage on it.
+      // Their heavy parts are independent, so they are done one per wave, NW at a time:
+      //   A  stage samples [480, 960) and estimate the CFO                      (parallel)
+      //   B  ring mean with this call's and the earlier calls' estimates entered (parallel, exact)
+      //   C  rotate, CP metrics                                                   (parallel)
+      //   D  CP averages in call order (a few flops), then FFT-128 / m0 / m1 / N_id_1 (parallel)
+      if (is_tracking && timer > 0 && !tracking_lost && peak_pos == kSlotLen && psr > a.psr_threshold) {
+        int64_t left = (n - pos) / kHalfFrame;
+        int nb = timer;
+        if (left < nb) nb = (int)left;
+        if (a.rec_cap - nrec < nb) nb = a.rec_cap - nrec;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        if (tid == 0) { // the CP averages live in wave 0 (it alone runs the SSS stage of a search call)
+          batch_avg[0] = m_norm_avg;
+          batch_avg[1] = m_ext_avg;
+        }
+        for (int done = 0; done < nb; done += NW) {
+          const int nr = (nb - done < NW) ? nb - done : NW;
+          const bool act = w < nr;
+          const int idx = done + w;                          // call within the batch
+          const int64_t hf0 = pos + (int64_t)idx * kHalfFrame;
+          float c = 0.f, mc = 0.f;
+          if (act) {
+            for (int i = lane; i < kSssLen; i += 64) RAWb[w][i] = ld_iq(x, n, hf0 + kSssBase + i);
+            c = cfo_estimate_wave(ltab.taps, RAWb[w] + (kSlotLen - kSymbolSz - kSssBase));
+            if (lane == 0) batch_cfo[w] = c;
+          }
+          __syncthreads();
+          if (done == 0) {
+            m_norm_avg = batch_avg[0];
+            m_ext_avg = batch_avg[1];
+          }
+          const uint32_t slot0 = cfo_i % kMovingAvgSz;
+          float ring_new = 0.f;
+          if (tid < nr) ring_new = batch_cfo[tid];
+          SssResult sres;
+          sres.cp = LT_CP_NORM; sres.m0 = -1; sres.m1 = -1; sres.n_id_1 = -1; sres.m0_value = sres.m1_value = 0.f;
+          v2f *out = nullptr;
+          float phase_inc = 0.f;
+          if (act) {
+            mc = moving_avg_wave(cfo_data, cfo_i + (uint32_t)w + 1u, slot0, batch_cfo, (uint32_t)w + 1u);
+            const float freq = -mc / (float)kSymbolSz;
+            phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+            for (int i = lane; i < kSssLen; i += 64) Sb[w][i] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + i, RAWb[w][i]);
+            const CpMetrics cm = cp_metrics_wave(Sb[w]);
+            if (lane == 0) batch_cp[w] = cm;
+            if (a.out_hf && n_emits + idx < a.out_cap) out = a.out_hf + ((int64_t)chain * a.out_cap + n_emits + idx) * kHalfFrame;
+          }
+          __syncthreads(); // every wave has read the ring; the CP metrics of the round are visible
+          if (tid < nr) cfo_data[(slot0 + tid) % kMovingAvgSz] = ring_new;
+          // CP averages in call order (every wave ends up with the state after the round)
+          float my_mn = 0.f, my_me = 0.f;
+          int my_cp = LT_CP_NORM;
+          for (int u = 0; u < nr; ++u) {
+            const CpMetrics cu = batch_cp[u];
+            const int cpu = cp_decide(cu, m_norm_avg, m_ext_avg);
+            if (u == w) {
+              my_cp = cpu;
+              my_mn = m_norm_avg;
+              my_me = m_ext_avg;
+            }
+          }
+          if (act) {
+            sss_after_cp_wave(Sb[w], my_cp, ltab, tab, Yb[w], sres);
+            if (lane == 0) {
+              uint32_t fl = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
+              if (sres.cp == LT_CP_EXT) fl |= LT_F_CP_EXT;
+              int cid = -1;
+              if (sres.n_id_1 >= 0) {
+                cid = 3 * sres.n_id_1 + n_id_2;
+                fl |= LT_F_TAG_CELL;
+              }
+              lt_record r;
+              r.in_pos = hf0; r.out_pos = hf0; r.channel = channel; r.n_id_2 = n_id_2;
+              r.call_idx = call_base + nrec + idx; r.flags = fl; r.peak_pos = kSlotLen; r.score = score;
+              r.psr = psr; r.peak_value = 0.f; r.cfo = c; r.mean_cfo = mc;
+              r.m_norm_avg = my_mn; r.m_ext_avg = my_me; r.m0_value = sres.m0_value;
+              r.m1_value = sres.m1_value; r.m0 = sres.m0; r.m1 = sres.m1; r.n_id_1 = sres.n_id_1; r.cell_id = cid;
+              r.psr_max = psr_max; r.timer = timer - 1 - idx;
+              recs[nrec + idx] = r;
+            }
+            if (out)
+              for (int i = lane; i < kHalfFrame; i += 64) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
+          }
+          cfo_i += (uint32_t)nr;
+        }
+        if (nb > 0) {
+          timer -= nb;
+          nrec += nb;
+          n_emits += nb;
+          if (grid_k >= 0) grid_k += nb;
+          pos += (int64_t)nb * kHalfFrame;
+          continue;
+        }
+      }
+    }
     uint32_t flags = 0;
     float peak_value = 0.f;
 
