@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[2]; with N GPUs it is configs[3] scaled, 64 chan
 each rank owns 64 independent 1.92 Msps capture channels of 1 s each, built from the four
 bundled fixtures (decimated to 1.92 Msps, seeded rotation, looped, AWGN 20 dB, every 8th
 channel noise only), resident in HBM before the timed region.  One step = one pass of the
-fused PSS->SSS chain kernel over the whole batch (state reset + kernel).  Channels are
+PSS->SSS path over the whole batch (state reset + lag-metric, edge-lag and replay kernels).  Channels are
 independent, so ranks never exchange data; torch.distributed is used for the barrier and the
 max-over-ranks of the wall time only.
 
@@ -30,7 +30,9 @@ FS = 1_920_000
 FIXTURES = [("lte_frame_6prb_cellid_123", 1, 123), ("lte_frame_25prb_cellid_124", 4, 124),
             ("lte_frame_50prb_cellid_125", 8, 125), ("lte_frame_100prb_cellid_369", 16, 369)]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-ALGO_BYTES_PER_SAMPLE = 8.0  # cf32 read once, all three roots + SSS served from it
+ALGO_BYTES_PER_SAMPLE = 8.0  # SURVEY 8(d), whole path: cf32 read once, all three roots + SSS served from it
+# per kernel of the bulk + replay execution (DESIGN.md "Kernels"): what each one must move at least
+METRIC_BYTES_PER_SAMPLE = 8.0 + 3 * 4.0  # lt_metric_kernel: cf32 in, |conv|^2 of three roots out
 
 
 def base_frames(lt):
@@ -153,6 +155,9 @@ def main():
 
     elapsed = sharding.max_over_ranks(dist, torch, elapsed, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    # per kernel: the library's own HIP events around each launch, of the last (up to 8) timed steps
+    phases = np.array([batch.phase_ms(k) for k in range(min(args.steps, 8))], dtype=np.float64)
+    phase_ms = phases.mean(axis=0) if len(phases) else np.full(3, np.nan)
 
     # correctness of what was timed: cell_id match on this rank's channels
     recs = batch.collect()
@@ -164,15 +169,35 @@ def main():
 
     if rank == 0:
         value = sharding.aggregate_msamp_per_s(world, n_ch, n, args.steps, elapsed)
-        achieved = ALGO_BYTES_PER_SAMPLE * n_ch * n / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    traffic = json.load(f).get("kernels", {})
             except (OSError, ValueError):
-                traffic = None
+                traffic = {}
+        # algorithmic bytes per launch of each kernel: the metric kernel reads every sample once
+        # and writes three floats per sample; the edge kernel reads 256 samples and writes 3 x 253 floats per
+        # window; the replay kernel reads the 9473 interior lags + 253 edge lags of every window it searches
+        # and 480 samples per tracked half-frame, and writes one 96-byte record per call
+        n_win = n // 9600
+        searched = sum(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
+        sss_ran = sum(int(((r["flags"] & lt.F_SSS_RAN) != 0).sum()) for r in recs)
+        calls = sum(len(r) for r in recs)
+        algo = {
+            "lt_metric_kernel": METRIC_BYTES_PER_SAMPLE * n_ch * n,
+            "lt_edge_kernel": float(n_ch * n_win) * (256 * 8 + 3 * 253 * 4),
+            "lt_chain_kernel": searched * 9726 * 4.0 + sss_ran * 480 * 8.0 + calls * 96.0,
+        }
+        kernels = []
+        for name, ms in zip(("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel"), phase_ms):
+            if not ms > 0:
+                continue
+            t = traffic.get(name, {}).get("hbm_bytes_per_launch")
+            kernels.append({"kernel": name, "ms": round(float(ms), 4), "algorithmic_bytes_per_launch": algo[name],
+                            "achieved": round(algo[name] / (ms * 1e-3) / 1e9, 2), "traffic": t})
+        dom = max(kernels, key=lambda k: k["ms"])
         out = {
             "metric": "IQ Msamp/s through PSS+SSS detect",
             "value": round(value, 3),
@@ -197,16 +222,21 @@ def main():
             },
             "cell_id_match_rate": match_rate,
             "realtime_factor": round(value * 1e6 / (world * n_ch * FS), 2),
+            # the dominant kernel = the one with the largest measured duration
             "roofline": {
                 "bound": "hbm",
-                "kernel": "lt_chain_kernel",
-                "achieved": round(achieved, 2),
+                "kernel": dom["kernel"],
+                "achieved": dom["achieved"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n_ch * n,
+                "frac": round(dom["achieved"] / HBM_PEAK_GBS, 5),
+                "traffic": dom["traffic"],
+                "kernel_ms": dom["ms"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "kernels": kernels,
+                # the whole path against its own floor (every sample read once, 8 B)
+                "path_ms": round(kernel_ms, 4),
+                "path_achieved": round(ALGO_BYTES_PER_SAMPLE * n_ch * n / (kernel_ms * 1e-3) / 1e9, 2),
             },
         }
         if not args.no_cpu_baseline:

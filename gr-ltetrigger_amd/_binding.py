@@ -42,7 +42,7 @@ EXPORTS = [
     "lt_sss_N_id_1", "lt_sync_get_cell_id",
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
-    "lt_batch_get_halfframes", "lt_batch_last_kernel_ms",
+    "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
 
@@ -114,6 +114,7 @@ def lib():
     L.lt_batch_enable_halfframes.argtypes = [vp, i64]
     L.lt_batch_get_halfframes.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.lt_batch_last_kernel_ms.argtypes = [vp, C.POINTER(f32)]
+    L.lt_batch_phase_ms.argtypes = [vp, i32, C.POINTER(f32)]
     L.lt_decim_create.argtypes = [pp, i32, i32]
     L.lt_decim_free.argtypes = [vp]
     L.lt_decim_free.restype = None
@@ -342,6 +343,13 @@ class Batch:
         _check(lib().lt_batch_get_halfframes(self._h, chain, out.ctypes.data_as(C.c_void_p),
                                              self._hf_cap, C.byref(n)), "lt_batch_get_halfframes")
         return out[: n.value]
+
+    def phase_ms(self, runs_back=0):
+        """(lag-metric kernel, edge-lag kernel, per-chain kernel) device times in ms of the run
+        `runs_back` runs ago (the last 8 runs are kept)."""
+        ms = (C.c_float * 3)()
+        _check(lib().lt_batch_phase_ms(self._h, int(runs_back), ms), "lt_batch_phase_ms")
+        return tuple(float(v) for v in ms)
 
     def last_kernel_ms(self):
         ms = C.c_float()

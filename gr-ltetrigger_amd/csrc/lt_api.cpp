@@ -149,7 +149,12 @@ struct lt_batch {
   float *d_metric = nullptr; // bulk + replay mode: [3][n_channels][max_samples]
   float *d_edge = nullptr;   // bulk + replay mode: [3][n_channels][max_samples / 9600][256]
   int mode = 1;              // 0 fused chain kernel, 1 bulk metric kernel + replay kernel
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, metric kernel done, edge kernel done, end
+  static constexpr int kPhaseRing = 8;
+  hipEvent_t ev[kPhaseRing][4] = {};
+  bool ev_bulk[kPhaseRing] = {};
+  uint64_t n_runs = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; // = ev[last run][0], [3]
   bool ran = false;
   int ablate = 0;
   unsigned long long *d_prof = nullptr;
@@ -502,8 +507,10 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_count, sizeof(int) * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
-  if (e == hipSuccess) e = hipEventCreate(&b->ev0);
-  if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  for (int i = 0; i < lt_batch::kPhaseRing && e == hipSuccess; ++i)
+    for (int j = 0; j < 4 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
+  b->ev0 = b->ev[0][0];
+  b->ev1 = b->ev[0][3];
   if (e != hipSuccess) {
     lt_batch_free(b);
     return fail(LT_ERROR, "lt_batch_create: %s", hipGetErrorString(e));
@@ -525,8 +532,9 @@ void lt_batch_free(lt_batch *b)
   if (b->d_metric) (void)hipFree(b->d_metric);
   if (b->d_edge) (void)hipFree(b->d_edge);
   if (b->d_prof) (void)hipFree(b->d_prof);
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  for (auto &set : b->ev)
+    for (hipEvent_t e : set)
+      if (e) (void)hipEventDestroy(e);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -611,16 +619,45 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
     const size_t max_windows = (size_t)b->max_samples / 9600 + 1;
     if (!b->d_edge) HIP_TRY(hipMalloc(&b->d_edge, sizeof(float) * 3 * (size_t)b->n_channels * max_windows * 256));
     L.edge = b->d_edge;
+    L.ev_metric_done = b->ev[b->n_runs % lt_batch::kPhaseRing][1];
+    L.ev_edge_done = b->ev[b->n_runs % lt_batch::kPhaseRing][2];
     L.edge_ch_stride = (int64_t)max_windows * 256;
     L.edge_root_stride = (int64_t)b->n_channels * L.edge_ch_stride;
     L.metric_ch_stride = b->max_samples;
     L.metric_root_stride = (int64_t)b->n_channels * b->max_samples;
   }
+  const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
+  b->ev_bulk[slot] = L.metric != nullptr;
+  b->ev0 = b->ev[slot][0];
+  b->ev1 = b->ev[slot][3];
+  b->n_runs++;
   HIP_TRY(hipEventRecord(b->ev0, s));
   HIP_TRY(lt::launch_chain(L, s));
   HIP_TRY(hipEventRecord(b->ev1, s));
   b->last_stream = s;
   b->ran = true;
+  return LT_OK;
+}
+
+int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[3])
+{
+  if (!b || !ms) return fail(LT_ERROR_INVALID_INPUTS, "lt_batch_phase_ms: null argument");
+  if (runs_back < 0 || runs_back >= lt_batch::kPhaseRing || (uint64_t)runs_back >= b->n_runs)
+    return fail(LT_ERROR_INVALID_INPUTS, "lt_batch_phase_ms: run %d back is not on record (kept: the last %d of %llu runs)",
+                runs_back, lt_batch::kPhaseRing, (unsigned long long)b->n_runs);
+  int rc = use_device(b->device);
+  if (rc) return rc;
+  const int slot = (int)((b->n_runs - 1 - (uint64_t)runs_back) % lt_batch::kPhaseRing);
+  hipEvent_t *e = b->ev[slot];
+  HIP_TRY(hipEventSynchronize(e[3]));
+  ms[0] = ms[1] = 0.f;
+  if (b->ev_bulk[slot]) {
+    HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], e[2], e[3]));
+  } else {
+    HIP_TRY(hipEventElapsedTime(&ms[2], e[0], e[3]));
+  }
   return LT_OK;
 }
 

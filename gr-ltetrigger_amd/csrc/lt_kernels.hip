@@ -922,6 +922,7 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
     } else if (total > 0) {
       return hipErrorInvalidValue;
     }
+    if (L.ev_metric_done) (void)hipEventRecord(L.ev_metric_done, stream);
     {
       EdgeArgs e;
       e.iq = a.iq;
@@ -938,6 +939,7 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
         hipLaunchKernelGGL(lt_edge_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, e);
       }
     }
+    if (L.ev_edge_done) (void)hipEventRecord(L.ev_edge_done, stream);
     if (L.ablate) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
     else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
   } else if (L.ablate) {

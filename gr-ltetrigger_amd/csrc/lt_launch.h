@@ -31,6 +31,8 @@ struct ChainLaunch {
   float *edge = nullptr;          // device, [3][n_channels][max_windows][256]: grid edge lags (bulk + replay mode)
   int64_t edge_ch_stride = 0;
   int64_t edge_root_stride = 0;
+  hipEvent_t ev_metric_done = nullptr; // optional: recorded after the lag-metric kernel / after the edge kernel
+  hipEvent_t ev_edge_done = nullptr;
   int n_cus = 256;      // compute units of the device (grid of the persistent metric kernel)
   int ablate = 0;       // diagnostics only
   void *prof = nullptr; // diagnostics only: 8 x uint64 on the device

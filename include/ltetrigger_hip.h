@@ -193,6 +193,10 @@ int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain);
 int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, int64_t *count);
 /* Device time of the chain kernel of the last run, in milliseconds (HIP events on the run's stream). */
 int lt_batch_last_kernel_ms(lt_batch *b, float *ms);
+/* The same, per kernel, of the run `runs_back` runs ago (0 = the last one; the last 8 are kept):
+ * ms[0] = lag-metric kernel, ms[1] = grid edge-lag kernel, ms[2] = per-chain (replay, or fused)
+ * kernel; the first two are 0 in fused mode. */
+int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[3]);
 
 /* ------------------------------------------------------------------ decimating FIR */
 /* gnuradio.filter.rational_resampler_ccc(interpolation=1, decimation=N) with its default taps

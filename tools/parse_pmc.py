@@ -20,34 +20,46 @@ def counter(run, kernel_substr, name):
     return vals
 
 
+KERNELS = ("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel")
+
+
+def median(v):
+    return sorted(v)[len(v) // 2] if v else None
+
+
 out = {}
-for run, kern in (("mix", "lt_chain_kernel"), ("decim", "lt_decim_kernel")):
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        v = counter(f"{run}_{c}", kern, c)
-        out[f"{run}_{c}"] = v
-        print(run, c, "per launch (counter units):", v)
-# units: FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B? print raw and derive with
-# the decimator, whose true read volume is known (64 ch * 1.92e6 * 8 B)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    out[f"decim_{c}"] = counter(f"decim_{c}", "lt_decim_kernel", c)
+    print("decim", c, "per launch (counter units):", out[f"decim_{c}"])
+    for k in KERNELS:
+        out[f"{k}_{c}"] = counter(f"mix_{c}", k, c)
+        print(k, c, "per launch (counter units):", out[f"{k}_{c}"])
+# The counters come in units that depend on the access width on gfx950 (MI355X_MICROARCH.md: FETCH_SIZE
+# reads 1/2 of a 16 B/lane stream): calibrate them on the decimator, whose true volume is known
+# (64 ch * 1.92e6 * 8 B read with the same 8 B/lane coalesced loads, 1/8 of it written).
 true_read = 64 * 1_920_000 * 8
 true_write = true_read // 8
-if out["decim_FETCH_SIZE"] and out["mix_FETCH_SIZE"]:
-    fd = sorted(out["decim_FETCH_SIZE"])[len(out["decim_FETCH_SIZE"]) // 2]
-    wd = sorted(out["decim_WRITE_SIZE"])[len(out["decim_WRITE_SIZE"]) // 2] if out["decim_WRITE_SIZE"] else None
-    fm = sorted(out["mix_FETCH_SIZE"])[len(out["mix_FETCH_SIZE"]) // 2]
-    wm = sorted(out["mix_WRITE_SIZE"])[len(out["mix_WRITE_SIZE"]) // 2] if out["mix_WRITE_SIZE"] else None
+fd, wd = median(out["decim_FETCH_SIZE"]), median(out["decim_WRITE_SIZE"])
+if fd:
     bytes_per_fetch_unit = true_read / fd
     bytes_per_write_unit = (true_write / wd) if wd else None
     print(f"calibration: decimator reads {true_read} B = {fd} FETCH units -> {bytes_per_fetch_unit:.1f} B/unit")
     if wd:
         print(f"calibration: decimator writes {true_write} B = {wd} WRITE units -> {bytes_per_write_unit:.1f} B/unit")
-    hbm_read = fm * bytes_per_fetch_unit
-    hbm_write = wm * bytes_per_write_unit if (wm is not None and bytes_per_write_unit) else 0.0
-    print(f"lt_chain_kernel per launch: read {hbm_read / 1e6:.1f} MB, write {hbm_write / 1e6:.1f} MB "
-          f"(algorithmic 983.04 MB)")
-    res = {"hbm_bytes_per_launch": hbm_read + hbm_write, "read_bytes": hbm_read, "write_bytes": hbm_write,
-           "fetch_units": fm, "write_units": wm, "bytes_per_fetch_unit": bytes_per_fetch_unit,
-           "bytes_per_write_unit": bytes_per_write_unit,
+    res = {"kernels": {}, "bytes_per_fetch_unit": bytes_per_fetch_unit, "bytes_per_write_unit": bytes_per_write_unit,
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on tools/probe.py --mode mix; "
-                     "units calibrated on lt_decim_kernel (known 983.04 MB read with the same 8 B/lane loads)"}
+                     "units calibrated on lt_decim_kernel (known 983.04 MB read with 8 B/lane loads, 122.88 MB written)"}
+    total = 0.0
+    for k in KERNELS:
+        fm, wm = median(out[f"{k}_FETCH_SIZE"]), median(out[f"{k}_WRITE_SIZE"])
+        if fm is None:
+            continue
+        rd = fm * bytes_per_fetch_unit
+        wr = wm * bytes_per_write_unit if (wm is not None and bytes_per_write_unit) else 0.0
+        print(f"{k} per launch: read {rd / 1e6:.1f} MB, write {wr / 1e6:.1f} MB")
+        res["kernels"][k] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+                             "fetch_units": fm, "write_units": wm}
+        total += rd + wr
+    res["hbm_bytes_per_launch"] = total
     with open(os.path.join(root, "traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
