@@ -24,6 +24,10 @@ namespace lt {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Tracked-path stages run on one wave at a time and are long: kept out of line so that their register
+// needs do not add to those of the per-window search loop they are called from.
+#define LT_OUTLINE __device__ __attribute__((noinline))
+
 constexpr int kThreads = 512;
 constexpr int kThreadsReplay = 256; // workgroup of the replay kernel (bulk + replay mode)
 constexpr int kWaves = kThreads / 64;
@@ -674,7 +678,7 @@ __device__ __forceinline__ float sum4_lanes(float v, int base)
 // partial sums (m mod 8) combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) -- lanes 0..7 / 8..15 hold the
 // partial sums of the two halves and meet in an xor butterfly; cfo = arg(conj(y0) y1) / pi.
 // h, r: 128 entries each (LDS or global).
-__device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
+LT_OUTLINE float cfo_estimate_wave(const v2f *h, const v2f *r)
 {
   const int lane = threadIdx.x & 63;
   v2f y = {0.f, 0.f};
@@ -713,15 +717,15 @@ __device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 // `n_new` entries starting at ring index `new_idx` (wrapping) are taken from new_vals[0..n_new) instead of
 // the ring: entries that are being written by this call and, in the batched tracked path, by the calls
 // before it in the batch.
-__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
-                                                 uint32_t n_new, unsigned long long *slow_count = nullptr);
+LT_OUTLINE float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
+                                 uint32_t n_new, unsigned long long *slow_count = nullptr);
 __device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val,
                                                  unsigned long long *slow_count = nullptr)
 {
   return moving_avg_wave(ring, npts, new_idx, &new_val, 1u, slow_count);
 }
-__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
-                                                 uint32_t n_new, unsigned long long *slow_count)
+LT_OUTLINE float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
+                                 uint32_t n_new, unsigned long long *slow_count)
 {
   if (!npts) return 0.0f;
   if (npts > (uint32_t)kMovingAvgSz) npts = kMovingAvgSz;
@@ -795,7 +799,7 @@ struct CpMetrics {
   float m[2]; // M_norm, M_ext of this half-frame (already the per-hypothesis ratios)
   float r[2]; // R_norm, R_ext (tie break)
 };
-__device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480);
+LT_OUTLINE CpMetrics cp_metrics_wave(const v2f *win480);
 // EMA update and decision of srslte_sync_detect_cp from one half-frame's metrics
 __device__ __forceinline__ int cp_decide(const CpMetrics &c, float &m_norm_avg, float &m_ext_avg)
 {
@@ -811,7 +815,7 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
   const CpMetrics c = cp_metrics_wave(win480);
   return cp_decide(c, m_norm_avg, m_ext_avg);
 }
-__device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480)
+LT_OUTLINE CpMetrics cp_metrics_wave(const v2f *win480)
 {
   const int lane = threadIdx.x & 63;
   float pr = 0.f, pp = 0.f;
@@ -1023,7 +1027,7 @@ __device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_,
 
 // sss_impl::work after the CP decision: FFT-128 of the SSS symbol, m0/m1 search, N_id_1 (one wave,
 // Y = 62 bins of LDS scratch owned by that wave)
-__device__ __forceinline__ void sss_after_cp_wave(const v2f *S, int cp, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
+LT_OUTLINE void sss_after_cp_wave(const v2f *S, int cp, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
                                                   v2f *Y, SssResult &r)
 {
   r.cp = cp;

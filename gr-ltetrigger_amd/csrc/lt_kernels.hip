@@ -48,6 +48,10 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   constexpr int NT = kBulk ? kThreadsReplay : kThreads; // threads
   constexpr int NL = kConvLen / NT;                     // lags per thread
   ChainArgs a = a_in;
+  unsigned long long *elapsed_out = nullptr; // diagnostics (flag 256): this chain's shader clocks, product build included
+  if (a.prof && (a.ablate & 256)) elapsed_out = a.prof + (size_t)(blockIdx.x % a.n_channels * 3 + blockIdx.x / a.n_channels) * 24 + 23;
+  const unsigned long long clk0 = elapsed_out ? __builtin_amdgcn_s_memtime() : 0;
+  a.ablate &= ~256;
   if (!kDiag) {
     a.ablate = 0;
     a.prof = nullptr;
@@ -133,21 +137,23 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
 
   // replay mode: thread's 19 lags of the window at q: interior from P, edge lags from the grid table
   // (window index k >= 0) or left alone (k < 0: the caller computes them)
-  constexpr int kTailTid0 = kHalfFrame - (NL - 1) * NT; // thread owning lag 9600 in its last slot (384)
+  constexpr int kTailTid0 = kHalfFrame - (NL - 1) * NT; // thread owning lag 9600 in its last slot
   auto load_slice = [&](float (&m)[kBulk ? NL : 1], int64_t q, int k) {
-    if (kDiag && (a.ablate & 1)) { // diagnostics: no HBM reads
+    if constexpr (kBulk) {
+      if (kDiag && (a.ablate & 1)) { // diagnostics: no HBM reads
 #pragma unroll
-      for (int i = 0; i < (kBulk ? NL : 1); ++i) m[i] = (float)((tid * 7 + i) & 15);
-      return;
+        for (int i = 0; i < (kBulk ? NL : 1); ++i) m[i] = (float)((tid * 7 + i) & 15);
+        return;
+      }
+      const float *__restrict__ Pq = P + q + tid;
+#pragma unroll
+      for (int i = 1; i < NL - 1; ++i) m[i] = Pq[i * NT];
+      const float *__restrict__ Ek = EP + (int64_t)(k < 0 ? 0 : k) * 256;
+      if (tid >= kSymbolSz - 1) m[0] = Pq[0];
+      else if (k >= 0) m[0] = Ek[tid];
+      if (tid < kTailTid0) m[NL - 1] = Pq[(NL - 1) * NT];
+      else if (k >= 0 && tid < kTailTid0 + 126) m[NL - 1] = Ek[kSymbolSz - 1 + tid - kTailTid0];
     }
-    const float *__restrict__ Pq = P + q + tid;
-#pragma unroll
-    for (int i = 1; i < NL - 1; ++i) m[i] = Pq[i * NT];
-    const float *__restrict__ Ek = EP + (int64_t)(k < 0 ? 0 : k) * 256;
-    if (tid >= kSymbolSz - 1) m[0] = Pq[0];
-    else if (k >= 0) m[0] = Ek[tid];
-    if (tid < kTailTid0) m[NL - 1] = Pq[(NL - 1) * NT];
-    else if (k >= 0 && tid < kTailTid0 + 126) m[NL - 1] = Ek[kSymbolSz - 1 + tid - kTailTid0];
   };
   while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
     if constexpr (kBulk) {
@@ -164,6 +170,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
         int nb = timer;
         if (left < nb) nb = (int)left;
         if (a.rec_cap - nrec < nb) nb = a.rec_cap - nrec;
+        const unsigned long long tb_ = profp ? __builtin_amdgcn_s_memtime() : 0;
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         if (tid == 0) { // the CP averages live in wave 0 (it alone runs the SSS stage of a search call)
           batch_avg[0] = m_norm_avg;
@@ -239,6 +246,10 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
           }
           cfo_i += (uint32_t)nr;
         }
+        if (profp) {
+          prof[16] += __builtin_amdgcn_s_memtime() - tb_;
+          prof[17] += 1;
+        }
         if (nb > 0) {
           timer -= nb;
           nrec += nb;
@@ -251,9 +262,67 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
     }
     uint32_t flags = 0;
     float peak_value = 0.f;
+    bool have_result = false; // replay mode: this call's search has been done by the idle loop below
+    if constexpr (kBulk) {
+      // ---- idle chain (nothing over the threshold lately, still on the capture's 9600-sample grid):
+      // every call searches its window, misses, and moves on by 9600 samples -- general_work without
+      // the emit branch (lib/pss_impl.cc:163-182, 217).  That is what nearly all chains do nearly all
+      // the time, so it gets a loop of its own that keeps nothing but the EMA and the prefetched
+      // slice in registers; the first window that fires is handed to the general code below with its
+      // search result.
+      if (!is_tracking && score == 0 && !tracking_lost && grid_k >= 0 && !(kDiag && a.ablate)) {
+        bool fired = false;
+        while (pos + kHalfFrame <= n && nrec < a.rec_cap) {
+          float met[NL];
+          if (pf_pos == pos && pf_edges) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) met[i] = pfm[i];
+          } else {
+            load_slice(met, pos, grid_k);
+          }
+          float *mirror = AVG_ + buf * kAvgLen;
+          bulk_search_ema<NT, NL>(met, ema, mirror, bs.tmax[buf], bs.tidx[buf]);
+          pf_pos = pos + kHalfFrame; // a miss leads there
+          pf_edges = true;
+          if (pf_pos + kHalfFrame <= n) load_slice(pfm, pf_pos, grid_k + 1);
+          else pf_pos = -1;
+          const SearchResult r = bulk_search_tail<NT, NL>(ema, mirror, bs.tmax[buf], bs.tidx[buf], bs.sl, nullptr);
+          buf ^= 1;
+          timer = a.track_every;
+          peak_pos = r.peak_pos;
+          psr = r.psr;
+          peak_value = r.peak_value;
+          if (tid == 0) psr_data[psr_i % kMovingAvgSz] = psr;
+          psr_i++;
+          if (psr > a.psr_threshold) {
+            fired = true;
+            break;
+          }
+          if (psr > psr_max) psr_max = psr;
+          if (tid == 0) {
+            lt_record rec;
+            rec.in_pos = pos; rec.out_pos = -1; rec.channel = channel; rec.n_id_2 = n_id_2;
+            rec.call_idx = call_base + nrec; rec.flags = LT_F_SEARCHED; rec.peak_pos = peak_pos; rec.score = 0;
+            rec.psr = psr; rec.peak_value = peak_value; rec.cfo = 0.f; rec.mean_cfo = 0.f;
+            rec.m_norm_avg = m_norm_avg; rec.m_ext_avg = m_ext_avg; rec.m0_value = 0.f;
+            rec.m1_value = 0.f; rec.m0 = -1; rec.m1 = -1; rec.n_id_1 = -1; rec.cell_id = -1;
+            rec.psr_max = psr_max; rec.timer = timer;
+            recs[nrec] = rec;
+          }
+          nrec++;
+          grid_k++;
+          pos += kHalfFrame;
+        }
+        if (!fired) continue; // out of samples or of record space
+        have_result = true;
+        flags |= LT_F_SEARCHED;
+      }
+    }
 
     // ---- lib/pss_impl.cc:163-172
-    if (!is_tracking || timer == 0) {
+    if (have_result) {
+      // searched above
+    } else if (!is_tracking || timer == 0) {
       timer = a.track_every;
       unsigned long long t0_ = profp ? __builtin_amdgcn_s_memtime() : 0;
       SearchResult r;
@@ -481,7 +550,8 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   }
 
   if (profp && tid == 0)
-    for (int i = 0; i < 24; ++i) a.prof[(size_t)chain * 24 + i] = prof[i];
+    for (int i = 0; i < 23; ++i) a.prof[(size_t)chain * 24 + i] = prof[i];
+  if (elapsed_out && tid == 0) *elapsed_out = __builtin_amdgcn_s_memtime() - clk0;
   // ---- store state
   __syncthreads();
 #pragma unroll
@@ -940,9 +1010,9 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
       }
     }
     if (L.ev_edge_done) (void)hipEventRecord(L.ev_edge_done, stream);
-    if (L.ablate) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
+    if (L.ablate & ~256) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
     else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
-  } else if (L.ablate) {
+  } else if (L.ablate & ~256) {
     a.metric = nullptr;
     hipLaunchKernelGGL((lt_chain_kernel<true, false>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
   } else {

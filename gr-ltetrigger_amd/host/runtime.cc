@@ -37,7 +37,7 @@ void block::set_history(unsigned h)
 {
   if (h < 1) h = 1;
   // zero history at stream start: pre-fill with h-1 zeros in front of item 0
-  if (d_nread != 0 || !d_in.empty() && d_in_abs0 + (int64_t)d_in.size() > 0)
+  if (d_nread != 0 || (!d_in.empty() && d_in_abs0 + (int64_t)d_in.size() > 0))
     throw std::runtime_error("set_history after start is not supported");
   d_history = h;
   d_in.assign(h - 1, gr_complex(0, 0));

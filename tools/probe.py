@@ -69,6 +69,22 @@ def main():
     nemit_tr = sum(int((((r["flags"] & lt.F_SSS_RAN) != 0)).sum()) for r in recs)
     per_chain_search = max(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
     k = float(np.median(ms))
+    if args.ablate & 256:
+        import ctypes
+        nchains = args.channels * 3
+        prof = (ctypes.c_ulonglong * (nchains * 24))()
+        lt.lib().lt_debug_get_profile(b._h, prof)
+        el = np.array(prof[:], dtype=np.float64).reshape(nchains, 24)[:, 23] / 1e3
+        kinds = []
+        for c in range(nchains):
+            r = recs[c]
+            tr = int(((r['flags'] & lt.F_SSS_RAN) != 0).sum())
+            kinds.append('tracked' if tr > 20 else 'search')
+        kinds = np.array(kinds)
+        for kd in ('tracked', 'search'):
+            v = el[kinds == kd]
+            if v.size:
+                print(f'{kd} chains ({v.size}): elapsed kclk min {v.min():.0f} median {np.median(v):.0f} max {v.max():.0f}')
     if args.ablate & 8:
         import ctypes
         nchains = args.channels * 3
@@ -86,6 +102,7 @@ def main():
                   f"; per tracked emit ({int(p[c, 13])}): " +
                   ", ".join(f"{n}={p[c, 8 + i] / ne:.0f}" for i, n in enumerate(tnames)) +
                   f" | wave0: cfo={p[c, 9] / ne:.0f} ringmean={p[c, 21] / ne:.0f} (slow path {int(p[c, 22])}x) | sss: cp={p[c, 17] / ne:.0f} dft={p[c, 18] / ne:.0f} bar={p[c, 19] / ne:.0f} m0m1={p[c, 20] / ne:.0f}" +
+                  f" | batches: {int(p[c, 17])} x {p[c, 16] / max(p[c, 17], 1):.0f} clk" +
                   " | conv: " + ", ".join(f"{n}={p[c, 14 + i] / nw:.0f}" for i, n in
                   enumerate(["inputs+barrier", "transforms", "metric+barriers"])))
     print(f"ablate={args.ablate} mode={args.mode} channels={args.channels} n={n}: kernel median {k:.3f} ms (min {min(ms):.3f}); "
