@@ -285,3 +285,73 @@ def test_fft_filter_equals_direct_form_filter(lt, oracle, frames_192):
             assert np.array_equal(a[f], d[f]), f"chain {c} field {f}"
         for f in METRIC_FIELDS:
             np.testing.assert_allclose(a[f], d[f], rtol=1e-5, atol=0)
+
+
+def test_chain_degenerate_signals(lt, oracle):
+    """Inputs whose lag metric is flat, monotone or made of a few spikes: an all-zero channel (exact
+    arg-max ties), a slow amplitude ramp on a tone (main lobe hundreds of lags wide -> the wide-lobe
+    path of the replay kernel), noise whose level jumps by 60 dB every half-frame.
+    Both execution modes against the oracle, every record field.  (Signals with symmetric, equal-valued
+    maxima or plateaus -- a constant, a pure tone, isolated impulses -- are left out: which of the twins wins is decided by the last bit
+    of the lag metric, which is only pinned to 1e-4.)"""
+    n = 12 * 9600 + 4321
+    t = np.arange(n)
+    rng = np.random.default_rng(11)
+    rows = [
+        np.zeros(n, np.complex64),
+        ((t / n) * np.exp(2j * np.pi * 0.01 * t)).astype(np.complex64),
+        siggen.awgn(rng, n, 1e-3) * (1.0 + 1e3 * (t // 9600 % 2)),
+    ]
+    iq = np.stack([r.astype(np.complex64) for r in rows])
+    for kw in (dict(), dict(psr_threshold=1.2, track_after=2, track_every=3)):
+        b, got, want = _run_both(lt, oracle, iq, **kw)
+        for c in range(3 * len(rows)):
+            assert_records_match(got[c], want[c], f"{kw} chain {c}")
+
+
+def test_chain_state_carries_over_runs(lt, oracle):
+    """Consecutive lt_batch_run calls continue the chains (EMA vector, score, rings, CP averages):
+    two runs over the two halves of a capture whose cut lies on a call boundary of every chain give
+    the records of one run over the whole capture -- in both execution modes and across a mode switch."""
+    x, _, _ = load_frame("6prb")
+    full = siggen.loop_to(x, 50 * 9600)
+    # cut after 10 half-frames of noise: nothing has fired yet, so every chain has consumed exactly 96000 samples
+    rng = np.random.default_rng(5)
+    full = full.copy()
+    full[:10 * 9600] = siggen.awgn(rng, 10 * 9600, 1e-2)
+    cut = 10 * 9600
+    want = [oracle.chain_run(full, root) for root in range(3)]
+    for modes in ((1, 1), (0, 0), (1, 0), (0, 1)):
+        b = lt.Batch(1, full.size)
+        b.set_mode(modes[0])
+        b.run_host(full[None, :cut])
+        first = b.collect()
+        b.set_mode(modes[1])
+        b.run_host(full[None, cut:])
+        second = b.collect()
+        for root in range(3):
+            a, c = first[root], second[root].copy()
+            c["in_pos"] += cut
+            c["out_pos"] = np.where(c["out_pos"] >= 0, c["out_pos"] + cut, c["out_pos"])
+            got = np.concatenate([a, c])
+            assert_records_match(got, want[root], f"modes {modes} root {root}")
+
+
+def test_phase_timers(lt):
+    """lt_batch_phase_ms: three kernels in bulk + replay mode, one in fused mode; a ring of 8 runs."""
+    x, _, _ = load_frame("6prb")
+    iq = siggen.loop_to(x, 20 * 9600)[None, :]
+    b = lt.Batch(1, iq.shape[1])
+    with pytest.raises(RuntimeError):
+        b.phase_ms(0)
+    b.run_host(iq)
+    m, e, r = b.phase_ms(0)
+    assert m > 0 and e > 0 and r > 0
+    assert abs((m + e + r) - b.last_kernel_ms()) < 0.05 + 0.2 * b.last_kernel_ms()
+    b.set_mode(0)
+    b.run_host(iq)
+    m0, e0, r0 = b.phase_ms(0)
+    assert m0 == 0 and e0 == 0 and r0 > 0
+    assert b.phase_ms(1)[0] > 0  # the previous run is still on record
+    with pytest.raises(RuntimeError):
+        b.phase_ms(8)
