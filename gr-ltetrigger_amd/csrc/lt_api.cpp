@@ -612,7 +612,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
     L.n_cus = g_ctx[b->device].n_cus > 0 ? g_ctx[b->device].n_cus : 256;
   }
   L.prof = b->d_prof;
-  if (b->mode == 1 && (!(b->ablate & ~256) || (b->ablate & 128))) { // 128: diagnostics build of the replay kernel
+  if (b->mode == 1 && (!(b->ablate & 0xFF) || (b->ablate & 128))) { // 128: diagnostics build of the replay kernel
     if (!b->d_metric)
       HIP_TRY(hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples));
     L.metric = b->d_metric;

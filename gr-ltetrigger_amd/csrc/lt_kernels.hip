@@ -34,7 +34,9 @@ struct ChainArgs {
   const float *edge;          // bulk + replay mode: edge lags of the windows on the 9600-sample grid (lt_edge_kernel)
   int64_t edge_ch_stride;
   int64_t edge_root_stride;
-  int ablate;             // diagnostics only (tools/probe.py): 1 = skip the window load
+  int ablate;             // diagnostics only (tools/probe.py --ablate): bits 0-7 select the diagnostics build of the
+                          // chain kernel and switch parts of it off; 256 = per-chain clocks from the product
+                          // build; 512 / 1024 = lag-metric kernel without its stores / loads
   unsigned long long *prof; // diagnostics only: per-phase shader-clock sums of chain 0 (ablate & 8)
 };
 
@@ -51,7 +53,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   unsigned long long *elapsed_out = nullptr; // diagnostics (flag 256): this chain's shader clocks, product build included
   if (a.prof && (a.ablate & 256)) elapsed_out = a.prof + (size_t)(blockIdx.x % a.n_channels * 3 + blockIdx.x / a.n_channels) * 24 + 23;
   const unsigned long long clk0 = elapsed_out ? __builtin_amdgcn_s_memtime() : 0;
-  a.ablate &= ~256;
+  a.ablate &= 0xFF;
   if (!kDiag) {
     a.ablate = 0;
     a.prof = nullptr;
@@ -730,7 +732,7 @@ struct MetricArgs {
 constexpr int kMetricWaves = 12;                  // one 1024-sample block per wave at a time, three waves per SIMD
 constexpr int kMetricThreads = 64 * kMetricWaves; // ONE workgroup per CU: the tables below are shared by all 12 waves
 
-// kAbl: diagnostics only (LT_METRIC_ABL): 1 = no stores, 2 = no loads
+// kAbl: diagnostics only (tools/probe.py --ablate 512 / 1024): 1 = no stores, 2 = no loads
 template <int kAbl> __global__ __launch_bounds__(kMetricThreads) void lt_metric_kernel(MetricArgs a)
 {
   __shared__ v2f E[kMetricWaves * fft::kScratchW]; // one exchange area per wave (12 x 8.5 KB)
@@ -982,7 +984,7 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
       // persistent: one workgroup per CU (its LDS footprint allows no second one), blocks strided over all waves
       const int64_t need = (total + kMetricWaves - 1) / kMetricWaves;
       const unsigned grid = (unsigned)(need < L.n_cus ? need : L.n_cus);
-      static const int abl = getenv("LT_METRIC_ABL") ? atoi(getenv("LT_METRIC_ABL")) : 0; // diagnostics only
+      const int abl = ((L.ablate & 512) ? 1 : 0) | ((L.ablate & 1024) ? 2 : 0); // diagnostics only (tools/probe.py)
       switch (abl) {
       case 1: hipLaunchKernelGGL(lt_metric_kernel<1>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
       case 2: hipLaunchKernelGGL(lt_metric_kernel<2>, dim3(grid), dim3(kMetricThreads), 0, stream, m); break;
@@ -1010,9 +1012,9 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
       }
     }
     if (L.ev_edge_done) (void)hipEventRecord(L.ev_edge_done, stream);
-    if (L.ablate & ~256) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
+    if (L.ablate & 0xFF) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
     else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
-  } else if (L.ablate & ~256) {
+  } else if (L.ablate & 0xFF) {
     a.metric = nullptr;
     hipLaunchKernelGGL((lt_chain_kernel<true, false>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
   } else {

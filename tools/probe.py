@@ -17,7 +17,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mode", default="noise", choices=["noise", "clean", "mix", "decim"])
     ap.add_argument("--ablate", type=int, default=0,
-                    help="1 no window load, 2 no conv, 4 no reductions, 8 stamps, 16 direct-form filter, 32 no ring mean, 64 no sss stage")
+                    help="bit mask. Diagnostics build of the chain kernel (fused mode unless 128 is set): 1 no window / slice load, "
+                         "2 no matched filter (fused), 4 no reductions (fused), 8 in-kernel stamps, "
+                         "16 direct-form filter (fused), 32 no ring mean, 64 no SSS stage, 128 replay kernel instead of fused. "
+                         "Product kernels: 256 per-chain shader clocks, 512 / 1024 lag-metric kernel without stores / loads")
     ap.add_argument("--threshold", type=float, default=4.0)
     ap.add_argument("--fused", action="store_true", help="fused per-chain kernel instead of bulk + replay")
     args = ap.parse_args()
@@ -85,7 +88,7 @@ def main():
             v = el[kinds == kd]
             if v.size:
                 print(f'{kd} chains ({v.size}): elapsed kclk min {v.min():.0f} median {np.median(v):.0f} max {v.max():.0f}')
-    if args.ablate & 8:
+    if (args.ablate & 8) and (args.ablate & 0xFF):
         import ctypes
         nchains = args.channels * 3
         prof = (ctypes.c_ulonglong * (nchains * 24))()
