@@ -612,12 +612,27 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
     L.n_cus = g_ctx[b->device].n_cus > 0 ? g_ctx[b->device].n_cus : 256;
   }
   L.prof = b->d_prof;
-  if (b->mode == 1 && (!(b->ablate & 0xFF) || (b->ablate & 128))) { // 128: diagnostics build of the replay kernel
-    if (!b->d_metric)
-      HIP_TRY(hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples));
+  bool bulk = b->mode == 1 && (!(b->ablate & 0xFF) || (b->ablate & 128)); // 128: diagnostics build of the replay kernel
+  const size_t max_windows = (size_t)b->max_samples / 9600 + 1;
+  // the lag-metric kernel numbers its 897-sample blocks with 32 bits
+  if (bulk && (uint64_t)b->n_channels * ((uint64_t)n_samples / 897 + 1) >= (1ull << 31)) bulk = false;
+  if (bulk && (!b->d_metric || !b->d_edge)) {
+    // 12 B per sample of HBM for the lag metric: a batch that does not leave room for it runs fused
+    hipError_t e = hipSuccess;
+    if (!b->d_metric) e = hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples);
+    if (e == hipSuccess && !b->d_edge)
+      e = hipMalloc(&b->d_edge, sizeof(float) * 3 * (size_t)b->n_channels * max_windows * 256);
+    if (e != hipSuccess) {
+      (void)hipGetLastError(); // clear the sticky out-of-memory state
+      if (b->d_metric) (void)hipFree(b->d_metric);
+      if (b->d_edge) (void)hipFree(b->d_edge);
+      b->d_metric = b->d_edge = nullptr;
+      b->mode = 0;
+      bulk = false;
+    }
+  }
+  if (bulk) {
     L.metric = b->d_metric;
-    const size_t max_windows = (size_t)b->max_samples / 9600 + 1;
-    if (!b->d_edge) HIP_TRY(hipMalloc(&b->d_edge, sizeof(float) * 3 * (size_t)b->n_channels * max_windows * 256));
     L.edge = b->d_edge;
     L.ev_metric_done = b->ev[b->n_runs % lt_batch::kPhaseRing][1];
     L.ev_edge_done = b->ev[b->n_runs % lt_batch::kPhaseRing][2];

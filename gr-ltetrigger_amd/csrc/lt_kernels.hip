@@ -78,7 +78,6 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   constexpr int NW = NT / 64;
   __shared__ v2f RAWb[kBulk ? NW : 1][kBulk ? kSssLen : 1];
   __shared__ v2f Sb[kBulk ? NW : 1][kBulk ? kSssLen : 1];
-  __shared__ v2f Yb[kBulk ? NW : 1][kBulk ? 62 : 1];
   __shared__ float batch_cfo[NW];
   __shared__ CpMetrics batch_cp[NW];
   __shared__ float batch_avg[2];
@@ -225,7 +224,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
             }
           }
           if (act) {
-            sss_after_cp_wave(Sb[w], my_cp, ltab, tab, Yb[w], sres);
+            sres.cp = my_cp; // FFT-128 / m0 / m1 / N_id_1 feed nothing here: lt_sss_kernel fills them in afterwards
             if (lane == 0) {
               uint32_t fl = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
               if (sres.cp == LT_CP_EXT) fl |= LT_F_CP_EXT;
@@ -509,7 +508,10 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
         // state thread 0 stores; the other waves run ahead to the next barrier)
         SssResult s;
         s.cp = LT_CP_NORM; s.m0 = -1; s.m1 = -1; s.n_id_1 = -1; s.m0_value = s.m1_value = 0.f;
-        if (tid < 64 && !(kDiag && (a.ablate & 64))) s = sss_stage_wave(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
+        if (tid < 64 && !(kDiag && (a.ablate & 64))) {
+          if (kBulk) s.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg); // the SSS itself: lt_sss_kernel, afterwards
+          else s = sss_stage_wave(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
+        }
         LT_TSTAMP(12) // sss stage
         if (profp) prof[13] += 1;
         flags |= LT_F_SSS_RAN;
@@ -835,6 +837,70 @@ template <int kAbl> __global__ __launch_bounds__(kMetricThreads) void lt_metric_
   }
 }
 
+// ---------------------------------------------------------------- SSS of the tracked half-frames (bulk + replay mode)
+// srslte_sss_m0m1_partial + srslte_sss_N_id_1 (lib/sss_impl.cc:110-124) of every record whose half-frame
+// went through the SSS stage.  The replay kernel has done the sequential part (CFO ring mean, CP
+// averages and decision) and left mean_cfo and the CP flag in the record; m0 / m1 / N_id_1 / cell_id feed
+// nothing but the record, so they are computed here for all chains at once, one wave per record: rotate
+// the SSS symbol exactly as srslte_cfo_correct did (same table index, same products), FFT-128,
+// 31 + 31 correlations, table look-up -- the same device functions the fused kernel runs in line.
+struct SssArgs {
+  const v2f *iq;
+  int64_t n_samples;
+  int64_t ch_stride;
+  lt_record *recs;  // [n_chains][rec_cap]
+  int rec_cap;
+  const int *rec_count; // [n_chains]
+  const DeviceTables *tab;
+};
+
+__global__ __launch_bounds__(256) void lt_sss_kernel(SssArgs a)
+{
+  __shared__ LdsTables ltab;
+  __shared__ v2f SYM[4][kSymbolSz];
+  __shared__ v2f Y[4][62];
+  const int chain = blockIdx.y, n_id_2 = chain % 3, channel = chain / 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = blockIdx.x * 4 + w;
+  const int count = a.rec_count[chain];
+  if ((int)blockIdx.x * 4 >= count) return; // whole block beyond this chain's records
+  load_lds_tables(ltab, a.tab, n_id_2);
+  __syncthreads();
+  if (idx >= count) return;
+  lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
+  const uint32_t flags = rec->flags;
+  if (!(flags & LT_F_SSS_RAN)) return;
+  const int64_t hf0 = rec->out_pos;
+  const float mean_cfo = rec->mean_cfo;
+  const v2f *__restrict__ x = a.iq + (int64_t)channel * a.ch_stride;
+  const float freq = -mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
+  const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+  const int cp_len = (flags & LT_F_CP_EXT) ? 32 : 9;              // srslte_sync_set_cp
+  const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len;           // lib/sss_impl.cc:110
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = sss_idx + lane + 64 * k;
+    SYM[w][lane + 64 * k] = cfo_rotate(a.tab->cexptab, phase_inc, i, ld_iq(x, a.n_samples, hf0 + i));
+  }
+  SssResult r;
+  r.cp = 0;
+  sss_fft128_wave(SYM[w], ltab.tw128, Y[w]);
+  sss_m0m1_wave(Y[w], ltab, r);
+  r.n_id_1 = sss_n_id_1(a.tab, (uint32_t)r.m0, (uint32_t)r.m1);
+  if (lane == 0) {
+    rec->m0 = r.m0;
+    rec->m1 = r.m1;
+    rec->m0_value = r.m0_value;
+    rec->m1_value = r.m1_value;
+    rec->n_id_1 = r.n_id_1;
+    if (r.n_id_1 >= 0) {
+      rec->cell_id = 3 * r.n_id_1 + n_id_2; // srslte_sync_get_cell_id
+      rec->flags = flags | LT_F_TAG_CELL;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- window-edge lags on the 9600-sample grid
 // A window's first 127 and last 126 lags see its zero padding, so they are not in P.  A chain that has
 // not re-aligned yet (every chain that never fires, i.e. almost all of them) searches the windows
@@ -1014,6 +1080,18 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
     if (L.ev_edge_done) (void)hipEventRecord(L.ev_edge_done, stream);
     if (L.ablate & 0xFF) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
     else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
+    {
+      SssArgs q;
+      q.iq = a.iq;
+      q.n_samples = L.n_samples;
+      q.ch_stride = L.ch_stride;
+      q.recs = L.recs;
+      q.rec_cap = L.rec_cap;
+      q.rec_count = L.rec_count;
+      q.tab = L.tab;
+      if (L.rec_cap > 0)
+        hipLaunchKernelGGL(lt_sss_kernel, dim3((unsigned)((L.rec_cap + 3) / 4), (unsigned)(L.n_channels * 3)), dim3(256), 0, stream, q);
+    }
   } else if (L.ablate & 0xFF) {
     a.metric = nullptr;
     hipLaunchKernelGGL((lt_chain_kernel<true, false>), dim3(L.n_channels * 3), dim3(kThreads), 0, stream, a);
