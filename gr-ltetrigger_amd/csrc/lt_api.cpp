@@ -148,6 +148,7 @@ struct lt_batch {
   int64_t hf_cap = 0;
   float *d_metric = nullptr; // bulk + replay mode: [3][n_channels][max_samples]
   float *d_edge = nullptr;   // bulk + replay mode: [3][n_channels][max_samples / 9600][256]
+  void *d_cp = nullptr;      // bulk + replay mode: [n_channels*3][rec_cap] x 16 B
   int mode = 1;              // 0 fused chain kernel, 1 bulk metric kernel + replay kernel
   // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, metric kernel done, edge kernel done, end
   static constexpr int kPhaseRing = 8;
@@ -531,6 +532,7 @@ void lt_batch_free(lt_batch *b)
   if (b->d_hf) (void)hipFree(b->d_hf);
   if (b->d_metric) (void)hipFree(b->d_metric);
   if (b->d_edge) (void)hipFree(b->d_edge);
+  if (b->d_cp) (void)hipFree(b->d_cp);
   if (b->d_prof) (void)hipFree(b->d_prof);
   for (auto &set : b->ev)
     for (hipEvent_t e : set)
@@ -616,16 +618,18 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   const size_t max_windows = (size_t)b->max_samples / 9600 + 1;
   // the lag-metric kernel numbers its 897-sample blocks with 32 bits
   if (bulk && (uint64_t)b->n_channels * ((uint64_t)n_samples / 897 + 1) >= (1ull << 31)) bulk = false;
-  if (bulk && (!b->d_metric || !b->d_edge)) {
+  if (bulk && (!b->d_metric || !b->d_edge || !b->d_cp)) {
     // 12 B per sample of HBM for the lag metric: a batch that does not leave room for it runs fused
     hipError_t e = hipSuccess;
     if (!b->d_metric) e = hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples);
     if (e == hipSuccess && !b->d_edge)
       e = hipMalloc(&b->d_edge, sizeof(float) * 3 * (size_t)b->n_channels * max_windows * 256);
+    if (e == hipSuccess && !b->d_cp) e = hipMalloc(&b->d_cp, (size_t)16 * (size_t)b->n_channels * 3 * (size_t)b->rec_cap);
     if (e != hipSuccess) {
       (void)hipGetLastError(); // clear the sticky out-of-memory state
       if (b->d_metric) (void)hipFree(b->d_metric);
       if (b->d_edge) (void)hipFree(b->d_edge);
+  if (b->d_cp) (void)hipFree(b->d_cp);
       b->d_metric = b->d_edge = nullptr;
       b->mode = 0;
       bulk = false;
@@ -634,6 +638,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   if (bulk) {
     L.metric = b->d_metric;
     L.edge = b->d_edge;
+    L.cp_scratch = b->d_cp;
     L.ev_metric_done = b->ev[b->n_runs % lt_batch::kPhaseRing][1];
     L.ev_edge_done = b->ev[b->n_runs % lt_batch::kPhaseRing][2];
     L.edge_ch_stride = (int64_t)max_windows * 256;

@@ -24,9 +24,10 @@ namespace lt {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Tracked-path stages run on one wave at a time and are long: kept out of line so that their register
-// needs do not add to those of the per-window search loop they are called from.
-#define LT_OUTLINE __device__ __attribute__((noinline))
+// (Out-of-line device functions taking generic pointers to LDS are avoided on purpose: the compiler may
+// rebase such a pointer below the start of the array and add the difference back as an instruction
+// offset; for an array at LDS offset 0 the rebased flat address leaves the LDS aperture and faults.)
+#define LT_OUTLINE __device__ __forceinline__
 
 constexpr int kThreads = 512;
 constexpr int kThreadsReplay = 256; // workgroup of the replay kernel (bulk + replay mode)
@@ -714,18 +715,13 @@ LT_OUTLINE float cfo_estimate_wave(const v2f *h, const v2f *r)
 // ulp and below 2^53 of them, i.e. exactly representable in double -- the sequential sum rounds
 // nowhere, so any association gives the same bits and an xor butterfly over the wave is used.
 // Otherwise the sum runs strictly in index order through v_readlane.
-// `n_new` entries starting at ring index `new_idx` (wrapping) are taken from new_vals[0..n_new) instead of
-// the ring: entries that are being written by this call and, in the batched tracked path, by the calls
-// before it in the batch.
-LT_OUTLINE float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
-                                 uint32_t n_new, unsigned long long *slow_count = nullptr);
-__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val,
-                                                 unsigned long long *slow_count = nullptr)
-{
-  return moving_avg_wave(ring, npts, new_idx, &new_val, 1u, slow_count);
-}
-LT_OUTLINE float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
-                                 uint32_t n_new, unsigned long long *slow_count)
+// `n_new` entries starting at ring index `new_idx` (wrapping) are taken from new_val(0..n_new-1) instead of
+// the ring: the entry that is being written by this call and, in the batched tracked path, those of the
+// calls before it in the batch.  (A functor, not a pointer: a pointer that may be LDS or a local would
+// turn the reads into flat loads.)
+template <typename NewVal>
+__device__ __forceinline__ float moving_avg_wave_f(const float *ring, uint32_t npts, uint32_t new_idx, uint32_t n_new,
+                                                  NewVal new_val, unsigned long long *slow_count)
 {
   if (!npts) return 0.0f;
   if (npts > (uint32_t)kMovingAvgSz) npts = kMovingAvgSz;
@@ -737,7 +733,7 @@ LT_OUTLINE float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_
     const uint32_t i = lane + 64 * k;
     float f = (i < (uint32_t)kMovingAvgSz) ? ring[i] : 0.f;
     const uint32_t d = i >= new_idx ? i - new_idx : i + (uint32_t)kMovingAvgSz - new_idx; // distance past new_idx, wrapping
-    if (i < (uint32_t)kMovingAvgSz && d < n_new) f = new_vals[d];
+    if (i < (uint32_t)kMovingAvgSz && d < n_new) f = new_val(d);
     v[k] = (i < npts) ? f : 0.f; // x + 0.0 leaves the running sum unchanged
     const uint32_t bits = __float_as_uint(v[k]) & 0x7fffffffu;
     const uint32_t e = bits >> 23;
@@ -776,6 +772,17 @@ LT_OUTLINE float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_
   }
   return (float)(acc / (double)npts);
 }
+__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, float new_val,
+                                                 unsigned long long *slow_count = nullptr)
+{
+  return moving_avg_wave_f(ring, npts, new_idx, 1u, [new_val](uint32_t) { return new_val; }, slow_count);
+}
+// new values in an LDS array
+__device__ __forceinline__ float moving_avg_wave(const float *ring, uint32_t npts, uint32_t new_idx, const float *new_vals,
+                                                 uint32_t n_new, unsigned long long *slow_count = nullptr)
+{
+  return moving_avg_wave_f(ring, npts, new_idx, n_new, [new_vals](uint32_t d) { return new_vals[d]; }, slow_count);
+}
 
 // srslte_cfo_correct for sample i: tab[floor(i*freq*4096 mod 4096)] * v  (quirk q6)
 __device__ __forceinline__ v2f cfo_rotate(const cf32 *__restrict__ tab, float phase_inc, int i, v2f v)
@@ -799,7 +806,15 @@ struct CpMetrics {
   float m[2]; // M_norm, M_ext of this half-frame (already the per-hypothesis ratios)
   float r[2]; // R_norm, R_ext (tie break)
 };
-LT_OUTLINE CpMetrics cp_metrics_wave(const v2f *win480);
+typedef float v4f __attribute__((ext_vector_type(4)));
+LT_OUTLINE v4f cp_metrics_wave_v(const v2f *win480); // (M_norm, M_ext, R_norm, R_ext): in registers, no stack object
+__device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480)
+{
+  const v4f v = cp_metrics_wave_v(win480);
+  CpMetrics c;
+  c.m[0] = v.x; c.m[1] = v.y; c.r[0] = v.z; c.r[1] = v.w;
+  return c;
+}
 // EMA update and decision of srslte_sync_detect_cp from one half-frame's metrics
 __device__ __forceinline__ int cp_decide(const CpMetrics &c, float &m_norm_avg, float &m_ext_avg)
 {
@@ -815,7 +830,7 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
   const CpMetrics c = cp_metrics_wave(win480);
   return cp_decide(c, m_norm_avg, m_ext_avg);
 }
-LT_OUTLINE CpMetrics cp_metrics_wave(const v2f *win480)
+LT_OUTLINE v4f cp_metrics_wave_v(const v2f *win480)
 {
   const int lane = threadIdx.x & 63;
   float pr = 0.f, pp = 0.f;
@@ -855,10 +870,7 @@ LT_OUTLINE CpMetrics cp_metrics_wave(const v2f *win480)
     R[hyp] = r;
     M[hyp] = (c > 0.f) ? r / c : 0.f;
   }
-  CpMetrics out;
-  out.m[0] = M[0]; out.m[1] = M[1];
-  out.r[0] = R[0]; out.r[1] = R[1];
-  return out;
+  return v4f{M[0], M[1], R[0], R[1]};
 }
 
 // 128-point forward FFT of the SSS symbol on one wave: iterative radix-2 decimation in time with the

@@ -76,11 +76,8 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   __shared__ BulkShared<NT> bs;
   // replay mode, batched tracked emits: one half-frame per wave
   constexpr int NW = NT / 64;
-  __shared__ v2f RAWb[kBulk ? NW : 1][kBulk ? kSssLen : 1];
-  __shared__ v2f Sb[kBulk ? NW : 1][kBulk ? kSssLen : 1];
+  __shared__ v2f RAWb[kBulk ? NW : 1][kBulk ? kSymbolSz : 1]; // the PSS symbol of each wave's half-frame
   __shared__ float batch_cfo[NW];
-  __shared__ CpMetrics batch_cp[NW];
-  __shared__ float batch_avg[2];
 
   const int tid = threadIdx.x;
   // blocks c, c + n_channels, c + 2 n_channels are the three roots of channel c: with n_channels a
@@ -173,10 +170,6 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
         if (a.rec_cap - nrec < nb) nb = a.rec_cap - nrec;
         const unsigned long long tb_ = profp ? __builtin_amdgcn_s_memtime() : 0;
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        if (tid == 0) { // the CP averages live in wave 0 (it alone runs the SSS stage of a search call)
-          batch_avg[0] = m_norm_avg;
-          batch_avg[1] = m_ext_avg;
-        }
         for (int done = 0; done < nb; done += NW) {
           const int nr = (nb - done < NW) ? nb - done : NW;
           const bool act = w < nr;
@@ -184,66 +177,39 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
           const int64_t hf0 = pos + (int64_t)idx * kHalfFrame;
           float c = 0.f, mc = 0.f;
           if (act) {
-            for (int i = lane; i < kSssLen; i += 64) RAWb[w][i] = ld_iq(x, n, hf0 + kSssBase + i);
-            c = cfo_estimate_wave(ltab.taps, RAWb[w] + (kSlotLen - kSymbolSz - kSssBase));
+            for (int i = lane; i < kSymbolSz; i += 64) RAWb[w][i] = ld_iq(x, n, hf0 + (kSlotLen - kSymbolSz) + i);
+            c = cfo_estimate_wave(ltab.taps, RAWb[w]);
             if (lane == 0) batch_cfo[w] = c;
           }
           __syncthreads();
-          if (done == 0) {
-            m_norm_avg = batch_avg[0];
-            m_ext_avg = batch_avg[1];
-          }
           const uint32_t slot0 = cfo_i % kMovingAvgSz;
           float ring_new = 0.f;
           if (tid < nr) ring_new = batch_cfo[tid];
-          SssResult sres;
-          sres.cp = LT_CP_NORM; sres.m0 = -1; sres.m1 = -1; sres.n_id_1 = -1; sres.m0_value = sres.m1_value = 0.f;
           v2f *out = nullptr;
-          float phase_inc = 0.f;
           if (act) {
             mc = moving_avg_wave(cfo_data, cfo_i + (uint32_t)w + 1u, slot0, batch_cfo, (uint32_t)w + 1u);
-            const float freq = -mc / (float)kSymbolSz;
-            phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-            for (int i = lane; i < kSssLen; i += 64) Sb[w][i] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + i, RAWb[w][i]);
-            const CpMetrics cm = cp_metrics_wave(Sb[w]);
-            if (lane == 0) batch_cp[w] = cm;
             if (a.out_hf && n_emits + idx < a.out_cap) out = a.out_hf + ((int64_t)chain * a.out_cap + n_emits + idx) * kHalfFrame;
           }
-          __syncthreads(); // every wave has read the ring; the CP metrics of the round are visible
+          __syncthreads(); // every wave has read the ring
           if (tid < nr) cfo_data[(slot0 + tid) % kMovingAvgSz] = ring_new;
-          // CP averages in call order (every wave ends up with the state after the round)
-          float my_mn = 0.f, my_me = 0.f;
-          int my_cp = LT_CP_NORM;
-          for (int u = 0; u < nr; ++u) {
-            const CpMetrics cu = batch_cp[u];
-            const int cpu = cp_decide(cu, m_norm_avg, m_ext_avg);
-            if (u == w) {
-              my_cp = cpu;
-              my_mn = m_norm_avg;
-              my_me = m_ext_avg;
-            }
-          }
           if (act) {
-            sres.cp = my_cp; // FFT-128 / m0 / m1 / N_id_1 feed nothing here: lt_sss_kernel fills them in afterwards
+            // rotation, CP decision and SSS feed nothing here: lt_cp_kernel / lt_cp_scan_kernel / lt_sss_kernel
             if (lane == 0) {
-              uint32_t fl = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
-              if (sres.cp == LT_CP_EXT) fl |= LT_F_CP_EXT;
-              int cid = -1;
-              if (sres.n_id_1 >= 0) {
-                cid = 3 * sres.n_id_1 + n_id_2;
-                fl |= LT_F_TAG_CELL;
-              }
               lt_record r;
               r.in_pos = hf0; r.out_pos = hf0; r.channel = channel; r.n_id_2 = n_id_2;
-              r.call_idx = call_base + nrec + idx; r.flags = fl; r.peak_pos = kSlotLen; r.score = score;
+              r.call_idx = call_base + nrec + idx; r.flags = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
+              r.peak_pos = kSlotLen; r.score = score;
               r.psr = psr; r.peak_value = 0.f; r.cfo = c; r.mean_cfo = mc;
-              r.m_norm_avg = my_mn; r.m_ext_avg = my_me; r.m0_value = sres.m0_value;
-              r.m1_value = sres.m1_value; r.m0 = sres.m0; r.m1 = sres.m1; r.n_id_1 = sres.n_id_1; r.cell_id = cid;
+              r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+              r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
               r.psr_max = psr_max; r.timer = timer - 1 - idx;
               recs[nrec + idx] = r;
             }
-            if (out)
+            if (out) {
+              const float freq = -mc / (float)kSymbolSz;
+              const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
               for (int i = lane; i < kHalfFrame; i += 64) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
+            }
           }
           cfo_i += (uint32_t)nr;
         }
@@ -458,69 +424,98 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
                      : nullptr;
 
       if (is_tracking) {
-        unsigned long long tt_ = profp ? __builtin_amdgcn_s_memtime() : 0;
-#define LT_TSTAMP(i)                                             \
-  if (profp) {                                                   \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    prof[i] += t_ - tt_;                                         \
-    tt_ = t_;                                                    \
-  }
-        // stage half-frame samples [480, 960) once (coalesced); everything below reads LDS
-        // (by waves 1..7: wave 0 arrives last from the previous emission's m0/m1 search and finds
-        // the samples already in LDS)
-        for (int i = tid - 64; i >= 0 && i < kSssLen; i += NT - 64) RAW[i] = ld_iq(x, n, hf0 + kSssBase + i);
-        __syncthreads();
-        LT_TSTAMP(8) // stage raw samples
-        // srslte_pss_cfo_compute on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring
-        // update and mean_cfo(): every wave computes them redundantly, wave 0 keeps the ring
-        if (tid < 64) { // wave 0 alone: the other waves wait at the barrier instead of competing for issue slots
-          const float c = cfo_estimate_wave(ltab.taps, RAW + (kSlotLen - kSymbolSz - kSssBase));
-          LT_TSTAMP(9) // cfo estimate (wave 0)
-          const uint32_t slot = cfo_i % kMovingAvgSz;
-          const float mc = (kDiag && (a.ablate & 32))
-                               ? c
-                               : moving_avg_wave(cfo_data, cfo_i + 1, slot, c, profp ? &prof[22] : nullptr);
-          LT_TSTAMP(21) // ring mean (wave 0)
-          if (tid == 0) {
-            cfo_data[slot] = c;
-            sc.cfo = c;
-            sc.mean_cfo = mc;
+        if constexpr (kBulk) {
+          // replay mode: CFO estimate on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring update and
+          // mean_cfo() -- the chain's only emit-side state.  Rotation of the half-frame, CP decision and SSS
+          // feed nothing in this kernel: lt_cp_kernel / lt_cp_scan_kernel / lt_sss_kernel run them afterwards
+          // from out_pos and mean_cfo of the record.
+          if (tid < kSymbolSz) RAW[tid] = ld_iq(x, n, hf0 + (kSlotLen - kSymbolSz) + tid);
+          __syncthreads();
+          if (tid < 64) {
+            const float c = cfo_estimate_wave(ltab.taps, RAW);
+            const uint32_t slot = cfo_i % kMovingAvgSz;
+            const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c);
+            if (tid == 0) {
+              cfo_data[slot] = c;
+              sc.cfo = c;
+              sc.mean_cfo = mc;
+            }
           }
-        }
-        __syncthreads();
-        cfo_i++;
-        cfo = sc.cfo;
-        mean_cfo = sc.mean_cfo;
-        LT_TSTAMP(10) // cfo estimate + ring mean
-        // srslte_cfo_correct(out, out, -mean_cfo()/symbol_sz), lib/pss_impl.cc:204
-        const float freq = -mean_cfo / (float)kSymbolSz;
-        const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-        for (int i = tid; i < kSssLen; i += NT) S[i] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + i, RAW[i]);
-        if (out)
-          for (int i = tid; i < kHalfFrame; i += NT)
-            out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
-        __syncthreads();
-        LT_TSTAMP(11) // rotation
-        // srslte_pss_chest (lib/pss_impl.cc:206-209): its output is never consumed -- dropped.
+          __syncthreads();
+          cfo_i++;
+          cfo = sc.cfo;
+          mean_cfo = sc.mean_cfo;
+          if (out) {
+            const float freq = -mean_cfo / (float)kSymbolSz; // srslte_cfo_correct, lib/pss_impl.cc:204
+            const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+            for (int i = tid; i < kHalfFrame; i += NT) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
+          }
+          flags |= LT_F_SSS_RAN;
+        } else {
+          unsigned long long tt_ = profp ? __builtin_amdgcn_s_memtime() : 0;
+#define LT_TSTAMP(i)                                             \
+    if (profp) {                                                   \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+      prof[i] += t_ - tt_;                                         \
+      tt_ = t_;                                                    \
+    }
+          // stage half-frame samples [480, 960) once (coalesced); everything below reads LDS
+          // (by waves 1..7: wave 0 arrives last from the previous emission's m0/m1 search and finds
+          // the samples already in LDS)
+          for (int i = tid - 64; i >= 0 && i < kSssLen; i += NT - 64) RAW[i] = ld_iq(x, n, hf0 + kSssBase + i);
+          __syncthreads();
+          LT_TSTAMP(8) // stage raw samples
+          // srslte_pss_cfo_compute on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring
+          // update and mean_cfo(): every wave computes them redundantly, wave 0 keeps the ring
+          if (tid < 64) { // wave 0 alone: the other waves wait at the barrier instead of competing for issue slots
+            const float c = cfo_estimate_wave(ltab.taps, RAW + (kSlotLen - kSymbolSz - kSssBase));
+            LT_TSTAMP(9) // cfo estimate (wave 0)
+            const uint32_t slot = cfo_i % kMovingAvgSz;
+            const float mc = (kDiag && (a.ablate & 32))
+                                 ? c
+                                 : moving_avg_wave(cfo_data, cfo_i + 1, slot, c, profp ? &prof[22] : nullptr);
+            LT_TSTAMP(21) // ring mean (wave 0)
+            if (tid == 0) {
+              cfo_data[slot] = c;
+              sc.cfo = c;
+              sc.mean_cfo = mc;
+            }
+          }
+          __syncthreads();
+          cfo_i++;
+          cfo = sc.cfo;
+          mean_cfo = sc.mean_cfo;
+          LT_TSTAMP(10) // cfo estimate + ring mean
+          // srslte_cfo_correct(out, out, -mean_cfo()/symbol_sz), lib/pss_impl.cc:204
+          const float freq = -mean_cfo / (float)kSymbolSz;
+          const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+          for (int i = tid; i < kSssLen; i += NT) S[i] = cfo_rotate(tab->cexptab, phase_inc, kSssBase + i, RAW[i]);
+          if (out)
+            for (int i = tid; i < kHalfFrame; i += NT)
+              out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_iq(x, n, hf0 + i));
+          __syncthreads();
+          LT_TSTAMP(11) // rotation
+          // srslte_pss_chest (lib/pss_impl.cc:206-209): its output is never consumed -- dropped.
 
-        // ---- sss_impl::work, no tracking_lost tag on this half-frame (lib/sss_impl.cc:102-150)
-        // (wave 0 only: m0, m1, n_id_1 and the CP averages feed nothing but the record and the
-        // state thread 0 stores; the other waves run ahead to the next barrier)
-        SssResult s;
-        s.cp = LT_CP_NORM; s.m0 = -1; s.m1 = -1; s.n_id_1 = -1; s.m0_value = s.m1_value = 0.f;
-        if (tid < 64 && !(kDiag && (a.ablate & 64))) {
-          if (kBulk) s.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg); // the SSS itself: lt_sss_kernel, afterwards
-          else s = sss_stage_wave(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
-        }
-        LT_TSTAMP(12) // sss stage
-        if (profp) prof[13] += 1;
-        flags |= LT_F_SSS_RAN;
-        if (s.cp == LT_CP_EXT) flags |= LT_F_CP_EXT;
-        m0 = s.m0; m1 = s.m1; m0_value = s.m0_value; m1_value = s.m1_value;
-        n_id_1 = s.n_id_1;
-        if (n_id_1 >= 0) { // (m0, m1, n_id_1 are valid in wave 0, whose thread 0 writes the record)
-          cell_id = 3 * n_id_1 + n_id_2; // srslte_sync_get_cell_id
-          flags |= LT_F_TAG_CELL;
+          // ---- sss_impl::work, no tracking_lost tag on this half-frame (lib/sss_impl.cc:102-150)
+          // (wave 0 only: m0, m1, n_id_1 and the CP averages feed nothing but the record and the
+          // state thread 0 stores; the other waves run ahead to the next barrier)
+          SssResult s;
+          s.cp = LT_CP_NORM; s.m0 = -1; s.m1 = -1; s.n_id_1 = -1; s.m0_value = s.m1_value = 0.f;
+          if (tid < 64 && !(kDiag && (a.ablate & 64))) {
+            if (kBulk) s.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg); // the SSS itself: lt_sss_kernel, afterwards
+            else s = sss_stage_wave(S, ltab, tab, m_norm_avg, m_ext_avg, sc);
+          }
+          LT_TSTAMP(12) // sss stage
+          if (profp) prof[13] += 1;
+          flags |= LT_F_SSS_RAN;
+          if (s.cp == LT_CP_EXT) flags |= LT_F_CP_EXT;
+          m0 = s.m0; m1 = s.m1; m0_value = s.m0_value; m1_value = s.m1_value;
+          n_id_1 = s.n_id_1;
+          if (n_id_1 >= 0) { // (m0, m1, n_id_1 are valid in wave 0, whose thread 0 writes the record)
+            cell_id = 3 * n_id_1 + n_id_2; // srslte_sync_get_cell_id
+            flags |= LT_F_TAG_CELL;
+          }
         }
       } else {
         // tracking lost: tag the half-frame (lib/pss_impl.cc:210-214); sss resets on the tag
@@ -571,7 +566,10 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
     st->psr_i = psr_i; st->cfo_i = cfo_i;
     st->n_calls += nrec; st->n_emits += n_emits;
     st->psr = psr; st->psr_max = psr_max;
-    st->m_norm_avg = m_norm_avg; st->m_ext_avg = m_ext_avg;
+    if (!kBulk) { // (replay mode: lt_cp_scan_kernel owns the CP averages)
+      st->m_norm_avg = m_norm_avg;
+      st->m_ext_avg = m_ext_avg;
+    }
     a.rec_count[chain] = nrec;
   }
 }
@@ -837,6 +835,96 @@ template <int kAbl> __global__ __launch_bounds__(kMetricThreads) void lt_metric_
   }
 }
 
+// ---------------------------------------------------------------- CP length of the tracked half-frames (bulk + replay mode)
+// srslte_sync_detect_cp (lib/sss_impl.cc:104-108) in two steps.  Its correlations (per half-frame,
+// independent) run one wave per record on the half-frame rotated exactly as srslte_cfo_correct did; its
+// two exponential averages and the decision are a short scan per chain in call order, which also
+// resets them where the reference's sss block sees the tracking_lost tag (lib/sss_impl.cc:91-100) and
+// writes the averages into every record.  Neither feeds the PSS state machine of the replay kernel.
+struct CpArgs {
+  const v2f *iq;
+  int64_t n_samples;
+  int64_t ch_stride;
+  lt_record *recs;      // [n_chains][rec_cap]
+  int rec_cap;
+  const int *rec_count; // [n_chains]
+  CpMetrics *metrics;   // [n_chains][rec_cap] scratch
+  ChainState *state;    // [n_chains]
+  const DeviceTables *tab;
+  int n_chains;
+};
+
+__global__ __launch_bounds__(256) void lt_cp_kernel(CpArgs a)
+{
+  __shared__ v2f S[4][kSssLen];
+  const int chain = blockIdx.y, channel = chain / 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = blockIdx.x * 4 + w;
+  if (idx >= a.rec_count[chain]) return;
+  const lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
+  if (!(rec->flags & LT_F_SSS_RAN)) return;
+  const int64_t hf0 = rec->out_pos;
+  const v2f *__restrict__ x = a.iq + (int64_t)channel * a.ch_stride;
+  const float freq = -rec->mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
+  const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+  for (int i = lane; i < kSssLen; i += 64)
+    S[w][i] = cfo_rotate(a.tab->cexptab, phase_inc, kSssBase + i, ld_iq(x, a.n_samples, hf0 + kSssBase + i));
+  const CpMetrics cm = cp_metrics_wave(S[w]);
+  if (lane == 0) a.metrics[(int64_t)chain * a.rec_cap + idx] = cm;
+}
+
+// One wave per chain: 64 records at a time are fetched one per lane, then the wave walks them in call
+// order with wave-uniform arithmetic (v_readlane), every lane keeping the values of its own record.
+__global__ __launch_bounds__(64) void lt_cp_scan_kernel(CpArgs a)
+{
+  const int chain = blockIdx.x, lane = threadIdx.x;
+  ChainState *st = a.state + chain;
+  float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  const CpMetrics *cm = a.metrics + (int64_t)chain * a.rec_cap;
+  const int count = a.rec_count[chain];
+  for (int base = 0; base < count; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < count;
+    const uint32_t flags = valid ? recs[i].flags : 0u;
+    CpMetrics c;
+    c.m[0] = c.m[1] = c.r[0] = c.r[1] = 0.f;
+    if (flags & LT_F_SSS_RAN) c = cm[i];
+    float my_norm = 0.f, my_ext = 0.f;
+    bool my_ext_cp = false;
+    const int nj = (count - base < 64) ? count - base : 64;
+    for (int j = 0; j < nj; ++j) {
+      const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)flags, j);
+      bool ext = false;
+      if (fj & LT_F_TAG_LOST) { // the sss block resets on the tracking_lost tag (lib/sss_impl.cc:91-100)
+        m_norm_avg = 0.f;
+        m_ext_avg = 0.f;
+      }
+      if (fj & LT_F_SSS_RAN) {
+        CpMetrics cj;
+        cj.m[0] = rlane(c.m[0], j); cj.m[1] = rlane(c.m[1], j);
+        cj.r[0] = rlane(c.r[0], j); cj.r[1] = rlane(c.r[1], j);
+        ext = cp_decide(cj, m_norm_avg, m_ext_avg) == LT_CP_EXT;
+      }
+      if (lane == j) {
+        my_norm = m_norm_avg;
+        my_ext = m_ext_avg;
+        my_ext_cp = ext;
+      }
+    }
+    if (valid) {
+      recs[i].m_norm_avg = my_norm;
+      recs[i].m_ext_avg = my_ext;
+      if (my_ext_cp) recs[i].flags = flags | LT_F_CP_EXT;
+    }
+  }
+  if (lane == 0) {
+    st->m_norm_avg = m_norm_avg;
+    st->m_ext_avg = m_ext_avg;
+  }
+}
+
 // ---------------------------------------------------------------- SSS of the tracked half-frames (bulk + replay mode)
 // srslte_sss_m0m1_partial + srslte_sss_N_id_1 (lib/sss_impl.cc:110-124) of every record whose half-frame
 // went through the SSS stage.  The replay kernel has done the sequential part (CFO ring mean, CP
@@ -1089,8 +1177,23 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
       q.rec_cap = L.rec_cap;
       q.rec_count = L.rec_count;
       q.tab = L.tab;
-      if (L.rec_cap > 0)
-        hipLaunchKernelGGL(lt_sss_kernel, dim3((unsigned)((L.rec_cap + 3) / 4), (unsigned)(L.n_channels * 3)), dim3(256), 0, stream, q);
+      CpArgs c;
+      c.iq = a.iq;
+      c.n_samples = L.n_samples;
+      c.ch_stride = L.ch_stride;
+      c.recs = L.recs;
+      c.rec_cap = L.rec_cap;
+      c.rec_count = L.rec_count;
+      c.metrics = reinterpret_cast<CpMetrics *>(L.cp_scratch);
+      c.state = a.state;
+      c.tab = L.tab;
+      c.n_chains = L.n_channels * 3;
+      if (L.rec_cap > 0) {
+        const dim3 per_record((unsigned)((L.rec_cap + 3) / 4), (unsigned)(L.n_channels * 3));
+        hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, stream, c);
+        hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)c.n_chains), dim3(64), 0, stream, c);
+        hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, stream, q);
+      }
     }
   } else if (L.ablate & 0xFF) {
     a.metric = nullptr;
