@@ -157,7 +157,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
     # per kernel: the library's own HIP events around each launch, of the last (up to 8) timed steps
     phases = np.array([batch.phase_ms(k) for k in range(min(args.steps, 8))], dtype=np.float64)
-    phase_ms = phases.mean(axis=0) if len(phases) else np.full(3, np.nan)
+    phase_ms = phases.mean(axis=0) if len(phases) else np.full(4, np.nan)
 
     # correctness of what was timed: cell_id match on this rank's channels
     recs = batch.collect()
@@ -180,7 +180,7 @@ def main():
         # algorithmic bytes per launch of each kernel: the metric kernel reads every sample once
         # and writes three floats per sample; the edge kernel reads 256 samples and writes 3 x 253 floats per
         # window; the replay kernel reads the 9473 interior lags + 253 edge lags of every window it searches
-        # and 480 samples per tracked half-frame, and writes one 96-byte record per call
+        # and the 128-sample PSS symbol of every tracked half-frame, and writes one 96-byte record per call
         n_win = n // 9600
         searched = sum(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
         sss_ran = sum(int(((r["flags"] & lt.F_SSS_RAN) != 0).sum()) for r in recs)
@@ -188,10 +188,13 @@ def main():
         algo = {
             "lt_metric_kernel": METRIC_BYTES_PER_SAMPLE * n_ch * n,
             "lt_edge_kernel": float(n_ch * n_win) * (256 * 8 + 3 * 253 * 4),
-            "lt_chain_kernel": searched * 9726 * 4.0 + sss_ran * 480 * 8.0 + calls * 96.0,
+            "lt_chain_kernel": searched * 9726 * 4.0 + sss_ran * 128 * 8.0 + calls * 96.0,
+            # lt_cp_kernel + lt_cp_scan_kernel + lt_sss_kernel: 480 + 128 samples per tracked half-frame, the
+            # record read and written once each
+            "post_pass": sss_ran * (480 + 128) * 8.0 + calls * 2 * 96.0,
         }
         kernels = []
-        for name, ms in zip(("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel"), phase_ms):
+        for name, ms in zip(("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel", "post_pass"), phase_ms):
             if not ms > 0:
                 continue
             t = traffic.get(name, {}).get("hbm_bytes_per_launch")

@@ -345,9 +345,9 @@ class Batch:
         return out[: n.value]
 
     def phase_ms(self, runs_back=0):
-        """(lag-metric kernel, edge-lag kernel, per-chain kernel) device times in ms of the run
-        `runs_back` runs ago (the last 8 runs are kept)."""
-        ms = (C.c_float * 3)()
+        """(lag-metric kernel, edge-lag kernel, per-chain kernel, per-record post-pass kernels) device
+        times in ms of the run `runs_back` runs ago (the last 8 runs are kept)."""
+        ms = (C.c_float * 4)()
         _check(lib().lt_batch_phase_ms(self._h, int(runs_back), ms), "lt_batch_phase_ms")
         return tuple(float(v) for v in ms)
 

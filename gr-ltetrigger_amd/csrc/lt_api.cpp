@@ -150,12 +150,13 @@ struct lt_batch {
   float *d_edge = nullptr;   // bulk + replay mode: [3][n_channels][max_samples / 9600][256]
   void *d_cp = nullptr;      // bulk + replay mode: [n_channels*3][rec_cap] x 16 B
   int mode = 1;              // 0 fused chain kernel, 1 bulk metric kernel + replay kernel
-  // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, metric kernel done, edge kernel done, end
+  // events of the last kPhaseRing runs: [run % kPhaseRing][0..4] = start, metric kernel done, edge kernel done,
+  // replay kernel done, end
   static constexpr int kPhaseRing = 8;
-  hipEvent_t ev[kPhaseRing][4] = {};
+  hipEvent_t ev[kPhaseRing][5] = {};
   bool ev_bulk[kPhaseRing] = {};
   uint64_t n_runs = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr; // = ev[last run][0], [3]
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; // = ev[last run][0], [4]
   bool ran = false;
   int ablate = 0;
   unsigned long long *d_prof = nullptr;
@@ -509,9 +510,9 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
   for (int i = 0; i < lt_batch::kPhaseRing && e == hipSuccess; ++i)
-    for (int j = 0; j < 4 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
+    for (int j = 0; j < 5 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
   b->ev0 = b->ev[0][0];
-  b->ev1 = b->ev[0][3];
+  b->ev1 = b->ev[0][4];
   if (e != hipSuccess) {
     lt_batch_free(b);
     return fail(LT_ERROR, "lt_batch_create: %s", hipGetErrorString(e));
@@ -641,6 +642,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
     L.cp_scratch = b->d_cp;
     L.ev_metric_done = b->ev[b->n_runs % lt_batch::kPhaseRing][1];
     L.ev_edge_done = b->ev[b->n_runs % lt_batch::kPhaseRing][2];
+    L.ev_replay_done = b->ev[b->n_runs % lt_batch::kPhaseRing][3];
     L.edge_ch_stride = (int64_t)max_windows * 256;
     L.edge_root_stride = (int64_t)b->n_channels * L.edge_ch_stride;
     L.metric_ch_stride = b->max_samples;
@@ -649,7 +651,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
   b->ev_bulk[slot] = L.metric != nullptr;
   b->ev0 = b->ev[slot][0];
-  b->ev1 = b->ev[slot][3];
+  b->ev1 = b->ev[slot][4];
   b->n_runs++;
   HIP_TRY(hipEventRecord(b->ev0, s));
   HIP_TRY(lt::launch_chain(L, s));
@@ -659,7 +661,7 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
   return LT_OK;
 }
 
-int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[3])
+int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4])
 {
   if (!b || !ms) return fail(LT_ERROR_INVALID_INPUTS, "lt_batch_phase_ms: null argument");
   if (runs_back < 0 || runs_back >= lt_batch::kPhaseRing || (uint64_t)runs_back >= b->n_runs)
@@ -669,14 +671,15 @@ int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[3])
   if (rc) return rc;
   const int slot = (int)((b->n_runs - 1 - (uint64_t)runs_back) % lt_batch::kPhaseRing);
   hipEvent_t *e = b->ev[slot];
-  HIP_TRY(hipEventSynchronize(e[3]));
-  ms[0] = ms[1] = 0.f;
+  HIP_TRY(hipEventSynchronize(e[4]));
+  ms[0] = ms[1] = ms[3] = 0.f;
   if (b->ev_bulk[slot]) {
     HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
     HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
     HIP_TRY(hipEventElapsedTime(&ms[2], e[2], e[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], e[3], e[4]));
   } else {
-    HIP_TRY(hipEventElapsedTime(&ms[2], e[0], e[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], e[0], e[4]));
   }
   return LT_OK;
 }

@@ -1168,6 +1168,7 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
     if (L.ev_edge_done) (void)hipEventRecord(L.ev_edge_done, stream);
     if (L.ablate & 0xFF) hipLaunchKernelGGL((lt_chain_kernel<true, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
     else hipLaunchKernelGGL((lt_chain_kernel<false, true>), dim3(L.n_channels * 3), dim3(kThreadsReplay), 0, stream, a);
+    if (L.ev_replay_done) (void)hipEventRecord(L.ev_replay_done, stream);
     {
       SssArgs q;
       q.iq = a.iq;

@@ -33,6 +33,7 @@ struct ChainLaunch {
   int64_t edge_root_stride = 0;
   hipEvent_t ev_metric_done = nullptr; // optional: recorded after the lag-metric kernel / after the edge kernel
   hipEvent_t ev_edge_done = nullptr;
+  hipEvent_t ev_replay_done = nullptr; // ... / after the replay kernel (the per-record post-pass kernels follow)
   void *cp_scratch = nullptr;     // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics (bulk + replay mode)
   int n_cus = 256;      // compute units of the device (grid of the persistent metric kernel)
   int ablate = 0;       // diagnostics only

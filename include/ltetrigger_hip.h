@@ -168,7 +168,8 @@ void lt_batch_free(lt_batch *b);
 int lt_batch_reset(lt_batch *b);
 /* Execution strategy of lt_batch_run: 1 (default) = one bulk kernel computes the position-independent
  * lag metric of every channel for all three roots, a light per-chain kernel replays the windows;
- * 0 = everything fused in the per-chain kernel.  Same records (lag metric equal to ~1e-6). */
+ * 0 = everything fused in the per-chain kernel.  Same records (lag metric equal to ~1e-6).  Mode 1 needs
+ * 12 B of HBM per sample for the lag metric; a batch that cannot get it falls back to mode 0 for good. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 /* downlink_trigger_c.set_psr_threshold fan-out (python/downlink_trigger_c.py:63-69) */
 int lt_batch_set_psr_threshold(lt_batch *b, float threshold);
@@ -195,8 +196,9 @@ int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, i
 int lt_batch_last_kernel_ms(lt_batch *b, float *ms);
 /* The same, per kernel, of the run `runs_back` runs ago (0 = the last one; the last 8 are kept):
  * ms[0] = lag-metric kernel, ms[1] = grid edge-lag kernel, ms[2] = per-chain (replay, or fused)
- * kernel; the first two are 0 in fused mode. */
-int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[3]);
+ * kernel, ms[3] = the per-record post-pass kernels (CP length, SSS); only ms[2] is non-zero in fused
+ * mode. */
+int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4]);
 
 /* ------------------------------------------------------------------ decimating FIR */
 /* gnuradio.filter.rational_resampler_ccc(interpolation=1, decimation=N) with its default taps

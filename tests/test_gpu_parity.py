@@ -338,20 +338,20 @@ def test_chain_state_carries_over_runs(lt, oracle):
 
 
 def test_phase_timers(lt):
-    """lt_batch_phase_ms: three kernels in bulk + replay mode, one in fused mode; a ring of 8 runs."""
+    """lt_batch_phase_ms: four phases in bulk + replay mode, one in fused mode; a ring of 8 runs."""
     x, _, _ = load_frame("6prb")
     iq = siggen.loop_to(x, 20 * 9600)[None, :]
     b = lt.Batch(1, iq.shape[1])
     with pytest.raises(RuntimeError):
         b.phase_ms(0)
     b.run_host(iq)
-    m, e, r = b.phase_ms(0)
-    assert m > 0 and e > 0 and r > 0
-    assert abs((m + e + r) - b.last_kernel_ms()) < 0.05 + 0.2 * b.last_kernel_ms()
+    m, e, r, p = b.phase_ms(0)
+    assert m > 0 and e > 0 and r > 0 and p > 0
+    assert abs((m + e + r + p) - b.last_kernel_ms()) < 0.05 + 0.2 * b.last_kernel_ms()
     b.set_mode(0)
     b.run_host(iq)
-    m0, e0, r0 = b.phase_ms(0)
-    assert m0 == 0 and e0 == 0 and r0 > 0
+    m0, e0, r0, p0 = b.phase_ms(0)
+    assert m0 == 0 and e0 == 0 and p0 == 0 and r0 > 0
     assert b.phase_ms(1)[0] > 0  # the previous run is still on record
     with pytest.raises(RuntimeError):
         b.phase_ms(8)

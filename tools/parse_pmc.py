@@ -20,7 +20,8 @@ def counter(run, kernel_substr, name):
     return vals
 
 
-KERNELS = ("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel")
+KERNELS = ("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel", "lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")
+POST = ("lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")
 
 
 def median(v):
@@ -60,6 +61,9 @@ if fd:
         res["kernels"][k] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                              "fetch_units": fm, "write_units": wm}
         total += rd + wr
+    post = [res["kernels"][k] for k in POST if k in res["kernels"]]
+    if post:  # bench.py reports the three per-record kernels as one phase
+        res["kernels"]["post_pass"] = {f: sum(p[f] for p in post) for f in ("hbm_bytes_per_launch", "read_bytes", "write_bytes")}
     res["hbm_bytes_per_launch"] = total
     with open(os.path.join(root, "traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
