@@ -681,33 +681,83 @@ __global__ __launch_bounds__(128) void lt_sss_m0m1_kernel(const v2f *__restrict_
 // ---------------------------------------------------------------- decimating FIR
 // y[c][k] = sum_j taps[j] * x[c][k*D - j].  One thread per output sample; a block stages the
 // (64*D + ntaps) input samples it needs in LDS with coalesced loads.
-constexpr int kDecimOutPerBlock = 256;
+constexpr int kDecimThreads = 256;
+constexpr int kDecimOutPerThread = 2;
+constexpr int kDecimOutPerBlock = kDecimThreads * kDecimOutPerThread;
 
-__global__ __launch_bounds__(256) void lt_decim_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
-                                                       int64_t n_in, int64_t n_out, int D,
-                                                       const float *__restrict__ taps, int ntaps)
+// Row length (in samples) of the polyphase staging area: >= cols, and such that the D rows a 16-lane
+// group of the staging store touches start on distinct even banks (R = 16/D mod 32 for D | 16, else odd).
+__host__ __device__ inline int decim_row_len(int cols, int D)
 {
-  extern __shared__ v2f xs[]; // kDecimOutPerBlock*D + ntaps - 1 samples
-  const int c = blockIdx.y;
+  const int want = (D <= 16 && (16 % D) == 0) ? 16 / D : 1;
+  int R = cols;
+  while ((R & 31) != (want & 31)) ++R;
+  return R;
+}
+
+// y[c][k] = sum_j taps[j] x[c][k D - j], accumulated in tap order with an unfused multiply-add (the
+// oracle's and GNU Radio's generic kernel order).  The block's input span is staged in LDS phase by
+// phase (sample i at row i mod D, column i / D): for a given tap all lanes then read one row at
+// consecutive columns -- conflict-free, where the natural layout would put every D-th sample of a wave
+// on the same banks.  Two outputs per thread run as independent add chains.
+// kD = decimation known at compile time (4, 8, 16: the reference's rates), or 0: read it from the argument.
+template <int kD>
+__global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
+                                                                 int64_t n_in, int64_t n_out, int D_arg,
+                                                                 const float *__restrict__ taps, int ntaps, int R)
+{
+  extern __shared__ v2f xs[]; // D rows of R samples
+  const int D = kD ? kD : D_arg;
+  const int c = blockIdx.y, tid = threadIdx.x;
   const int64_t k0 = (int64_t)blockIdx.x * kDecimOutPerBlock;
   const v2f *xc = x + (int64_t)c * n_in;
-  const int64_t first = k0 * D - (ntaps - 1); // oldest input sample needed
-  const int span = kDecimOutPerBlock * D + ntaps - 1;
-  for (int i = threadIdx.x; i < span; i += blockDim.x) xs[i] = ld_iq(xc, n_in, first + i);
+  // oldest input sample needed, moved down to a multiple of D so that sample `first + i` has phase i mod D
+  const int lead = ((ntaps - 1 + D - 1) / D) * D; // >= ntaps - 1
+  const int64_t first = k0 * D - lead;
+  const int span = kDecimOutPerBlock * D + lead;
+  for (int i = tid; i < span; i += kDecimThreads) xs[(i % D) * R + i / D] = ld_iq(xc, n_in, first + i);
   __syncthreads();
-  const int64_t k = k0 + threadIdx.x;
-  if (k >= n_out) return;
-  // newest sample of output k sits at xs[(ntaps-1) + tid*D]
-  const v2f *p = xs + (ntaps - 1) + threadIdx.x * D;
-  float re = 0.f, im = 0.f;
-  for (int j = 0; j < ntaps; ++j) { // same order and rounding as the oracle: product then add
-    const v2f v = p[-j];
+  // newest sample of output k0 + o sits at i = lead + o D: row 0, column lead / D + o
+  float re[kDecimOutPerThread], im[kDecimOutPerThread];
+#pragma unroll
+  for (int o = 0; o < kDecimOutPerThread; ++o) re[o] = im[o] = 0.f;
+  const v2f *base = xs + lead / D + tid;
+  // tap j = q D + r reads sample i = lead + o D - j: row (-j) mod D = (D - r) mod D, column lead / D + o - q - (r > 0)
+  auto tap = [&](int j, const v2f *p) { // same order and rounding as the oracle: product, then add
     const float t = taps[j];
-    re = __fadd_rn(re, __fmul_rn(t, v.x));
-    im = __fadd_rn(im, __fmul_rn(t, v.y));
+#pragma unroll
+    for (int o = 0; o < kDecimOutPerThread; ++o) {
+      const v2f v = p[o * kDecimThreads];
+      re[o] = __fadd_rn(re[o], __fmul_rn(t, v.x));
+      im[o] = __fadd_rn(im[o], __fmul_rn(t, v.y));
+    }
+  };
+  if (kD) {
+    const int nq = ntaps / kD; // whole groups of D taps
+    for (int q = 0; q < nq; ++q) {
+      const v2f *pq = base - q;
+#pragma unroll
+      for (int r = 0; r < kD; ++r) tap(q * kD + r, pq + ((kD - r) % kD) * R - (r > 0));
+    }
+    const v2f *pq = base - nq;
+#pragma unroll
+    for (int r = 0; r < kD; ++r)
+      if (nq * kD + r < ntaps) tap(nq * kD + r, pq + ((kD - r) % kD) * R - (r > 0));
+  } else {
+    int row = 0, col = 0;
+    for (int j = 0; j < ntaps; ++j) {
+      tap(j, base + row * R + col);
+      if (--row < 0) {
+        row += D;
+        --col;
+      }
+    }
   }
-  v2f r = {re, im};
-  y[(int64_t)c * n_out + k] = r;
+#pragma unroll
+  for (int o = 0; o < kDecimOutPerThread; ++o) {
+    const int64_t k = k0 + tid + o * kDecimThreads;
+    if (k < n_out) y[(int64_t)c * n_out + k] = v2f{re[o], im[o]};
+  }
 }
 
 // ---------------------------------------------------------------- bulk lag metric (bulk + replay mode)
@@ -1256,10 +1306,20 @@ hipError_t launch_decim(const void *x, void *y, int n_channels, int64_t n_in, in
 {
   const int64_t n_out = n_in / D;
   if (n_out <= 0) return hipSuccess;
-  const size_t lds = sizeof(v2f) * (size_t)(kDecimOutPerBlock * D + ntaps - 1);
+  const int lead = ((ntaps - 1 + D - 1) / D) * D;
+  const int R = decim_row_len((kDecimOutPerBlock * D + lead + D - 1) / D, D);
+  const size_t lds = sizeof(v2f) * (size_t)D * (size_t)R;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  void (*kern)(const v2f *, v2f *, int64_t, int64_t, int, const float *, int, int) =
+      D == 4 ? lt_decim_kernel<4> : D == 8 ? lt_decim_kernel<8> : D == 16 ? lt_decim_kernel<16> : lt_decim_kernel<0>;
+  if (lds > 64 * 1024) { // (decimation 16: 70 KB)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   dim3 grid((unsigned)((n_out + kDecimOutPerBlock - 1) / kDecimOutPerBlock), (unsigned)n_channels);
-  hipLaunchKernelGGL(lt_decim_kernel, grid, dim3(256), lds, stream, reinterpret_cast<const v2f *>(x),
-                     reinterpret_cast<v2f *>(y), n_in, n_out, D, taps, ntaps);
+  hipLaunchKernelGGL(kern, grid, dim3(kDecimThreads), lds, stream, reinterpret_cast<const v2f *>(x),
+                     reinterpret_cast<v2f *>(y), n_in, n_out, D, taps, ntaps, R);
   return hipGetLastError();
 }
 

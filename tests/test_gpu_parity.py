@@ -141,6 +141,20 @@ def test_decimator_bit_exact(lt, oracle, decim):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("decim", [2, 3, 5, 12])
+def test_decimator_other_rates_and_ragged_lengths(lt, oracle, decim):
+    """Rates outside the reference's 4 / 8 / 16 take the kernel's generic path; input lengths that are
+    not a multiple of the rate or of the block size, several channels at once."""
+    rng = np.random.default_rng(decim)
+    dec = lt.Decim(decim)
+    assert np.array_equal(dec.taps().view(np.uint32), oracle.decim_taps(decim).view(np.uint32))
+    for n in (1, decim - 1, decim, 777, 512 * decim + 3, 20011):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        got, want = dec.run_host(x), oracle.decimate(x, decim)
+        assert got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"decim {decim} n {n}"
+
+
 def _run_both(lt, oracle, iq, **kw):
     """Both execution strategies of the batch (bulk + replay, fused) against the oracle; returns the
     default (bulk + replay) results after checking that the fused kernel agrees with the oracle too."""
