@@ -1,10 +1,12 @@
 // Device-side building blocks of the gfx950 LTE cell-search path.
 //
 // Work decomposition (one workgroup = one pss->sss chain = one (channel, N_id_2)):
-//   512 threads (8 wave64), thread `tid` owns the 19 consecutive lags [19*tid, 19*tid+19) of the
-//   9728-lag linear convolution of a 9600-sample half-frame window with the 128-tap PSS filter
-//   (512 * 19 = 9728 exactly).  The window sits zero-padded in LDS; the EMA of the lag metric
-//   lives in 19 registers per thread and never touches HBM between windows.
+//   fused kernel: 512 threads (8 wave64), thread `tid` owns the 19 consecutive lags [19*tid, 19*tid+19) of
+//   the 9728-lag linear convolution of a 9600-sample half-frame window with the 128-tap PSS filter
+//   (512 * 19 = 9728 exactly); the window sits zero-padded in LDS.
+//   replay kernel: 256 threads, thread `tid` owns lags tid, tid + 256, ... (38 of them), the order the
+//   precomputed lag metric arrives in.
+//   Either way the EMA of the lag metric lives in registers and never touches HBM between windows.
 //
 // Arithmetic rules: the library is built with -ffp-contract=off; the only fused operations are
 // the explicit FMAs of the matched filter and of the CFO rotation.  Everything downstream of the
@@ -24,9 +26,10 @@ namespace lt {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// (Out-of-line device functions taking generic pointers to LDS are avoided on purpose: the compiler may
-// rebase such a pointer below the start of the array and add the difference back as an instruction
-// offset; for an array at LDS offset 0 the rebased flat address leaves the LDS aperture and faults.)
+// Every device function is inlined.  (Out-of-line functions taking generic pointers to LDS were tried and
+// dropped: the compiler may rebase such a pointer below the start of the array and add the difference
+// back as an instruction offset; for an array at LDS offset 0 the rebased flat address leaves the LDS
+// aperture and the access faults.)
 #define LT_OUTLINE __device__ __forceinline__
 
 constexpr int kThreads = 512;

@@ -1,14 +1,18 @@
-// gfx950 kernels of the LTE cell-search hot path.
+// gfx950 kernels of the LTE cell-search hot path (DESIGN.md section 4).
 //
-//   lt_chain_kernel  -- the product's hot kernel: one persistent workgroup per (channel, N_id_2)
-//                       chain walks the whole capture half-frame by half-frame, running
-//                       pss_impl::general_work (lib/pss_impl.cc:155-223) and, on every emitted
-//                       half-frame, sss_impl::work (lib/sss_impl.cc:83-156), and writes one
-//                       lt_record per call.  IQ is read once from HBM into LDS; the 3 x 65 filter
-//                       taps are wave-uniform scalars; peak / side-lobe reductions are wavefront
-//                       shuffles; the EMA of the lag metric stays in registers.
-//   lt_find_kernel, lt_cfo_*, lt_sync_* -- single-call forms behind the srslte_* shaped C-ABI.
-//   lt_decim_kernel  -- decimating FIR in front of the path.
+// lt_batch_run, bulk + replay mode (default):
+//   lt_metric_kernel   -- |matched filter|^2 of every sample position for the three PSS roots, overlap-save
+//                         FFT-1024, one forward transform per block shared by the roots (chip-wide).
+//   lt_edge_kernel     -- the 253 zero-padding-affected lags of the windows on the 9600-sample grid.
+//   lt_chain_kernel<*, true> -- one workgroup per (channel, N_id_2) chain replays pss_impl::general_work
+//                         (lib/pss_impl.cc:155-223) over the capture: EMA of the lag metric in registers,
+//                         arg-max / main-lobe walk / PSR, score and tracking logic, CFO ring; one lt_record
+//                         per call.
+//   lt_cp_kernel, lt_cp_scan_kernel, lt_sss_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) of the tracked
+//                         half-frames, per record, after the replay (its results feed records only).
+// lt_batch_run, fused mode: lt_chain_kernel<*, false> does all of it in one persistent workgroup per chain.
+// lt_find_kernel, lt_cfo_*, lt_sync_*  -- single-call forms behind the srslte_* shaped C-ABI.
+// lt_decim_kernel -- decimating FIR in front of the path.
 #include "lt_device.h"
 
 namespace lt {
