@@ -30,7 +30,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // dropped: the compiler may rebase such a pointer below the start of the array and add the difference
 // back as an instruction offset; for an array at LDS offset 0 the rebased flat address leaves the LDS
 // aperture and the access faults.)
-#define LT_OUTLINE __device__ __forceinline__
 
 constexpr int kThreads = 512;
 constexpr int kThreadsReplay = 256; // workgroup of the replay kernel (bulk + replay mode)
@@ -682,7 +681,7 @@ __device__ __forceinline__ float sum4_lanes(float v, int base)
 // partial sums (m mod 8) combined as ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) -- lanes 0..7 / 8..15 hold the
 // partial sums of the two halves and meet in an xor butterfly; cfo = arg(conj(y0) y1) / pi.
 // h, r: 128 entries each (LDS or global).
-LT_OUTLINE float cfo_estimate_wave(const v2f *h, const v2f *r)
+__device__ __forceinline__ float cfo_estimate_wave(const v2f *h, const v2f *r)
 {
   const int lane = threadIdx.x & 63;
   v2f y = {0.f, 0.f};
@@ -810,7 +809,7 @@ struct CpMetrics {
   float r[2]; // R_norm, R_ext (tie break)
 };
 typedef float v4f __attribute__((ext_vector_type(4)));
-LT_OUTLINE v4f cp_metrics_wave_v(const v2f *win480); // (M_norm, M_ext, R_norm, R_ext): in registers, no stack object
+__device__ __forceinline__ v4f cp_metrics_wave_v(const v2f *win480); // (M_norm, M_ext, R_norm, R_ext): in registers, no stack object
 __device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480)
 {
   const v4f v = cp_metrics_wave_v(win480);
@@ -833,7 +832,7 @@ __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_a
   const CpMetrics c = cp_metrics_wave(win480);
   return cp_decide(c, m_norm_avg, m_ext_avg);
 }
-LT_OUTLINE v4f cp_metrics_wave_v(const v2f *win480)
+__device__ __forceinline__ v4f cp_metrics_wave_v(const v2f *win480)
 {
   const int lane = threadIdx.x & 63;
   float pr = 0.f, pp = 0.f;
@@ -1042,7 +1041,7 @@ __device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_,
 
 // sss_impl::work after the CP decision: FFT-128 of the SSS symbol, m0/m1 search, N_id_1 (one wave,
 // Y = 62 bins of LDS scratch owned by that wave)
-LT_OUTLINE void sss_after_cp_wave(const v2f *S, int cp, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
+__device__ __forceinline__ void sss_after_cp_wave(const v2f *S, int cp, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
                                                   v2f *Y, SssResult &r)
 {
   r.cp = cp;
