@@ -158,6 +158,10 @@ template <int kCtrl> __device__ __forceinline__ int dpp_i(int v)
   v = OP(v, dpp_i<0x122>(v)); /* row_ror:2 */  \
   v = OP(v, dpp_i<0x121>(v)); /* row_ror:1 */
 
+__device__ __forceinline__ float rlane_f(float v, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ int imin_(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 // max of non-NaN floats >= -FLT_MAX, through their ordered bit patterns is not possible for negative
@@ -178,14 +182,16 @@ __device__ __forceinline__ int wave_max_i(int v)
   const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
   return imax_(imax_(a, b), imax_(c, d));
 }
-// maximum of floats none of which is NaN (callers pass -FLT_MAX for "nothing")
+// maximum of floats none of which is NaN (callers pass -FLT_MAX for "nothing"): v_max_f32 with a DPP
+// operand per step, the four row results through v_readlane
 __device__ __forceinline__ float wave_max_f(float f)
 {
-  int v = __float_as_int(f);
-  LT_ROW_ALLREDUCE(v, fmax_bits_)
-  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  return __int_as_float(fmax_bits_(fmax_bits_(a, b), fmax_bits_(c, d)));
+  f = fmaxf(f, __int_as_float(dpp_i<0x128>(__float_as_int(f)))); // row_ror:8
+  f = fmaxf(f, __int_as_float(dpp_i<0x124>(__float_as_int(f)))); // row_ror:4
+  f = fmaxf(f, __int_as_float(dpp_i<0x122>(__float_as_int(f)))); // row_ror:2
+  f = fmaxf(f, __int_as_float(dpp_i<0x121>(__float_as_int(f)))); // row_ror:1
+  const float a = rlane_f(f, 0), b = rlane_f(f, 16), c = rlane_f(f, 32), d = rlane_f(f, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 // srslte_pss_find_pss on the window held in W (LDS, zero padded): lag metric, EMA(0.2),
@@ -539,6 +545,7 @@ __device__ __forceinline__ void bulk_search_ema(const float (&met)[NL], float (&
 // outside the lobe contributes it as it is; the lags inside the lobe belong to pl_ub - pl_lb threads,
 // whose remaining lags are looked up in the LDS mirror one by one (a handful for the usual narrow
 // lobe; lobes wider than 64 lags take a second barrier and a masked pass over the registers instead).
+// (Superseded in part: only threads whose own maximum lies inside the lobe are looked up.)
 template <int NT, int NL>
 __device__ __forceinline__ SearchResult bulk_search_tail(const float (&ema)[NL], const float *AVG, const float *tmax,
                                                          const int *tidx, float *wave_sl,
@@ -574,45 +581,64 @@ __device__ __forceinline__ SearchResult bulk_search_tail(const float (&ema)[NL],
   const float peak_value = AVG[peak];
   LT_BSTAMP(3) // arg-max
 
-  // main-lobe walk, 64 lags per step in each direction (see search_tail)
-  int pl_ub = 0, pl_lb = 0;
-  for (int base = peak + 1;; base += 64) {
-    const int u = base + lane;
-    bool stop = false;
-    if (u <= kConvLen - 1) stop = !(AVG[u + 1] <= AVG[u]) || u >= kConvLen - 1;
-    const unsigned long long m = __ballot(stop);
-    if (m) {
-      pl_ub = base + __builtin_ctzll(m);
-      break;
+  // main-lobe walk, 64 lags per step, both directions in the same turn (their LDS round trips overlap):
+  //   pl_ub = first u >= peak+1 with !(avg[u+1] <= avg[u]) or u >= 9727
+  //   pl_lb = last  l <= peak-1 with !(avg[l-1] <= avg[l]) or l <= 1      (0 when peak <= 2)
+  const float q_left = AVG[0];
+  int pl_ub = 0, pl_lb = 0, up_base = peak + 1, dn_base = peak - 1;
+  bool up_done = false, dn_done = !(peak > 2);
+  for (;;) {
+    unsigned long long mu = 0, md = 0;
+    if (!up_done) {
+      const int u = up_base + lane;
+      bool stop = false;
+      if (u <= kConvLen - 1) stop = !(AVG[u + 1] <= AVG[u]) || u >= kConvLen - 1;
+      mu = __ballot(stop);
     }
-  }
-  if (peak > 2) {
-    for (int base = peak - 1;; base -= 64) {
-      const int u = base - lane;
+    if (!dn_done) {
+      const int u = dn_base - lane;
       bool stop = false;
       if (u >= 1) stop = !(AVG[u - 1] <= AVG[u]) || u <= 1;
-      const unsigned long long m = __ballot(stop);
-      if (m) {
-        pl_lb = base - __builtin_ctzll(m);
-        break;
+      md = __ballot(stop);
+    }
+    if (!up_done) {
+      if (mu) {
+        pl_ub = up_base + __builtin_ctzll(mu);
+        up_done = true;
+      } else {
+        up_base += 64;
       }
     }
+    if (!dn_done) {
+      if (md) {
+        pl_lb = dn_base - __builtin_ctzll(md);
+        dn_done = true;
+      } else {
+        dn_base -= 64;
+      }
+    }
+    if (up_done && dn_done) break;
   }
-  const float q_left = AVG[0], q_right = AVG[pl_ub];
+  const float q_right = AVG[pl_ub];
   LT_BSTAMP(4) // walk
   float out = -FLT_MAX; // maximum over the valid lags outside [pl_lb, pl_ub)
   const int width = pl_ub - pl_lb;
   if (width <= 64) {
+    // A thread whose maximum lies outside the lobe contributes it as it is (its other lags are not above
+    // it); a thread whose maximum lies inside has its NL lags looked up in the mirror, one per lane.
 #pragma unroll
-    for (int k = 0; k < NT / 64; ++k)
-      if ((ti[k] < pl_lb || ti[k] >= pl_ub) && tv[k] > out) out = tv[k]; // (a thread without a maximum holds -FLT_MAX)
-    // the other lags of the threads that own the lobe's lags: candidate (lobe lag L, i) = (L mod 512) + 512 i
-    for (int c = lane; c < width * NL; c += 64) {
-      const int L = pl_lb + c / NL, i = c - (c / NL) * NL;
-      const int lag = (L & (NT - 1)) + i * NT;
-      if ((lag < pl_lb || lag >= pl_ub) && lag < kNLags) {
-        const float v = AVG[lag];
-        if (v > out) out = v;
+    for (int k = 0; k < NT / 64; ++k) {
+      const bool inside = ti[k] >= pl_lb && ti[k] < pl_ub;
+      if (!inside && tv[k] > out) out = tv[k]; // (a thread without a maximum holds -FLT_MAX, lag INT_MAX)
+      unsigned long long owners = __ballot(inside);
+      while (owners) {
+        const int t = __builtin_ctzll(owners) + 64 * k;
+        owners &= owners - 1;
+        const int lag = t + lane * NT;
+        if (lane < NL && (lag < pl_lb || lag >= pl_ub) && lag < kNLags) {
+          const float v = AVG[lag];
+          if (v > out) out = v;
+        }
       }
     }
     out = wave_max_f(out);
