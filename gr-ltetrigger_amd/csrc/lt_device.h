@@ -843,15 +843,23 @@ __device__ __forceinline__ CpMetrics cp_metrics_wave(const v2f *win480)
   c.m[0] = v.x; c.m[1] = v.y; c.r[0] = v.z; c.r[1] = v.w;
   return c;
 }
-// EMA update and decision of srslte_sync_detect_cp from one half-frame's metrics
-__device__ __forceinline__ int cp_decide(const CpMetrics &c, float &m_norm_avg, float &m_ext_avg)
+// EMA update and decision of srslte_sync_detect_cp from one half-frame's metrics, in three pieces so that
+// lt_cp_scan_kernel can form the state-independent products for 64 records at once:
+//   avg' = alpha * (M / 3) + (1 - alpha) * avg;   CP = avg_norm > avg_ext ? normal : avg_norm < avg_ext ? ext : by R
+constexpr float kCpAlpha = 0.1f;
+__device__ __forceinline__ float cp_avg_input(float m) { return __fmul_rn(kCpAlpha, m / 3.0f); }
+__device__ __forceinline__ float cp_avg_step(float input, float avg) { return __fadd_rn(input, __fmul_rn(1.0f - kCpAlpha, avg)); }
+__device__ __forceinline__ int cp_choose(float m_norm_avg, float m_ext_avg, float r_norm, float r_ext)
 {
-  const float alpha = 0.1f;
-  m_norm_avg = __fadd_rn(__fmul_rn(alpha, c.m[0] / 3.0f), __fmul_rn(1.0f - alpha, m_norm_avg));
-  m_ext_avg = __fadd_rn(__fmul_rn(alpha, c.m[1] / 3.0f), __fmul_rn(1.0f - alpha, m_ext_avg));
   if (m_norm_avg > m_ext_avg) return LT_CP_NORM;
   if (m_norm_avg < m_ext_avg) return LT_CP_EXT;
-  return (c.r[0] > c.r[1]) ? LT_CP_NORM : LT_CP_EXT;
+  return (r_norm > r_ext) ? LT_CP_NORM : LT_CP_EXT;
+}
+__device__ __forceinline__ int cp_decide(const CpMetrics &c, float &m_norm_avg, float &m_ext_avg)
+{
+  m_norm_avg = cp_avg_step(cp_avg_input(c.m[0]), m_norm_avg);
+  m_ext_avg = cp_avg_step(cp_avg_input(c.m[1]), m_ext_avg);
+  return cp_choose(m_norm_avg, m_ext_avg, c.r[0], c.r[1]);
 }
 __device__ __forceinline__ int cp_detect_wave(const v2f *win480, float &m_norm_avg, float &m_ext_avg)
 {

@@ -928,8 +928,10 @@ __global__ __launch_bounds__(256) void lt_cp_kernel(CpArgs a)
   if (lane == 0) a.metrics[(int64_t)chain * a.rec_cap + idx] = cm;
 }
 
-// One wave per chain: 64 records at a time are fetched one per lane, then the wave walks them in call
-// order with wave-uniform arithmetic (v_readlane), every lane keeping the values of its own record.
+// One wave per chain: 64 records at a time are fetched one per lane and everything that does not depend on
+// the running averages is formed in parallel; the wave then walks only the records that change the
+// averages (tracked half-frames, tracking_lost tags) in call order with wave-uniform arithmetic, every lane
+// keeping the state as of its own record; decisions and stores are per lane again.
 __global__ __launch_bounds__(64) void lt_cp_scan_kernel(CpArgs a)
 {
   const int chain = blockIdx.x, lane = threadIdx.x;
@@ -942,35 +944,34 @@ __global__ __launch_bounds__(64) void lt_cp_scan_kernel(CpArgs a)
     const int i = base + lane;
     const bool valid = i < count;
     const uint32_t flags = valid ? recs[i].flags : 0u;
+    const bool ran = (flags & LT_F_SSS_RAN) != 0;
     CpMetrics c;
     c.m[0] = c.m[1] = c.r[0] = c.r[1] = 0.f;
-    if (flags & LT_F_SSS_RAN) c = cm[i];
-    float my_norm = 0.f, my_ext = 0.f;
-    bool my_ext_cp = false;
-    const int nj = (count - base < 64) ? count - base : 64;
-    for (int j = 0; j < nj; ++j) {
-      const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)flags, j);
-      bool ext = false;
-      if (fj & LT_F_TAG_LOST) { // the sss block resets on the tracking_lost tag (lib/sss_impl.cc:91-100)
+    if (ran) c = cm[i];
+    const float in_norm = cp_avg_input(c.m[0]), in_ext = cp_avg_input(c.m[1]);
+    const unsigned long long run = __ballot(ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
+    float my_norm = m_norm_avg, my_ext = m_ext_avg; // state as of this lane's record
+    unsigned long long events = run | lost;
+    while (events) {
+      const int j = __builtin_ctzll(events);
+      events &= events - 1;
+      if ((lost >> j) & 1) { // the sss block resets on the tracking_lost tag (lib/sss_impl.cc:91-100)
         m_norm_avg = 0.f;
         m_ext_avg = 0.f;
       }
-      if (fj & LT_F_SSS_RAN) {
-        CpMetrics cj;
-        cj.m[0] = rlane(c.m[0], j); cj.m[1] = rlane(c.m[1], j);
-        cj.r[0] = rlane(c.r[0], j); cj.r[1] = rlane(c.r[1], j);
-        ext = cp_decide(cj, m_norm_avg, m_ext_avg) == LT_CP_EXT;
+      if ((run >> j) & 1) {
+        m_norm_avg = cp_avg_step(rlane(in_norm, j), m_norm_avg);
+        m_ext_avg = cp_avg_step(rlane(in_ext, j), m_ext_avg);
       }
-      if (lane == j) {
+      if (lane >= j) {
         my_norm = m_norm_avg;
         my_ext = m_ext_avg;
-        my_ext_cp = ext;
       }
     }
     if (valid) {
       recs[i].m_norm_avg = my_norm;
       recs[i].m_ext_avg = my_ext;
-      if (my_ext_cp) recs[i].flags = flags | LT_F_CP_EXT;
+      if (ran && cp_choose(my_norm, my_ext, c.r[0], c.r[1]) == LT_CP_EXT) recs[i].flags = flags | LT_F_CP_EXT;
     }
   }
   if (lane == 0) {
