@@ -149,11 +149,11 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
       }
       const float *__restrict__ Pq = P + q + tid;
 #pragma unroll
-      for (int i = 1; i < NL - 1; ++i) m[i] = Pq[i * NT];
+      for (int i = 1; i < NL - 1; ++i) m[i] = __builtin_nontemporal_load(&Pq[i * NT]); // read once
       const float *__restrict__ Ek = EP + (int64_t)(k < 0 ? 0 : k) * 256;
-      if (tid >= kSymbolSz - 1) m[0] = Pq[0];
+      if (tid >= kSymbolSz - 1) m[0] = __builtin_nontemporal_load(&Pq[0]);
       else if (k >= 0) m[0] = Ek[tid];
-      if (tid < kTailTid0) m[NL - 1] = Pq[(NL - 1) * NT];
+      if (tid < kTailTid0) m[NL - 1] = __builtin_nontemporal_load(&Pq[(NL - 1) * NT]);
       else if (k >= 0 && tid < kTailTid0 + 126) m[NL - 1] = Ek[kSymbolSz - 1 + tid - kTailTid0];
     }
   };
@@ -820,7 +820,7 @@ template <int kAbl> __global__ __launch_bounds__(kMetricThreads) void lt_metric_
       for (int r = 0; r < 16; ++r) xf[r] = fft::c32{(float)(l + r), (float)gb};
     } else if (base >= 0 && base + fft::kN <= a.n_samples) { // interior block: no bounds checks
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xf[r] = x[base + l + 64 * r];
+      for (int r = 0; r < 16; ++r) xf[r] = __builtin_nontemporal_load(&x[base + l + 64 * r]);
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) xf[r] = ld_iq(x, a.n_samples, base + l + 64 * r);
@@ -838,9 +838,9 @@ template <int kAbl> __global__ __launch_bounds__(kMetricThreads) void lt_metric_
       for (int r = 1; r < 16; ++r) s += v[r].x + v[r].y;
       if (s == 1234.5f) out[l + 64] = s;
     } else if (base + fft::kN <= a.n_samples) {
-      if (l == 63) out[127] = __fadd_rn(__fmul_rn(v[1].x, v[1].x), __fmul_rn(v[1].y, v[1].y)); // reg 1 = positions 64..127
+      if (l == 63) __builtin_nontemporal_store(__fadd_rn(__fmul_rn(v[1].x, v[1].x), __fmul_rn(v[1].y, v[1].y)), &out[127]); // reg 1 = positions 64..127
 #pragma unroll
-      for (int r = 2; r < 16; ++r) out[l + 64 * r] = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
+      for (int r = 2; r < 16; ++r) __builtin_nontemporal_store(__fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y)), &out[l + 64 * r]);
     } else {
 #pragma unroll
       for (int r = 1; r < 16; ++r) {
