@@ -911,10 +911,10 @@ struct CpArgs {
 __global__ __launch_bounds__(256) void lt_cp_kernel(CpArgs a)
 {
   __shared__ v2f S[4][kSssLen];
-  const int chain = blockIdx.y, channel = chain / 3;
+  const int chain = blockIdx.x, channel = chain / 3; // (chains along x: up to 2^31 - 1 of them)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = blockIdx.x * 4 + w;
+  const int idx = blockIdx.y * 4 + w;
   if (idx >= a.rec_count[chain]) return;
   const lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
   if (!(rec->flags & LT_F_SSS_RAN)) return;
@@ -1002,12 +1002,12 @@ __global__ __launch_bounds__(256) void lt_sss_kernel(SssArgs a)
   __shared__ LdsTables ltab;
   __shared__ v2f SYM[4][kSymbolSz];
   __shared__ v2f Y[4][62];
-  const int chain = blockIdx.y, n_id_2 = chain % 3, channel = chain / 3;
+  const int chain = blockIdx.x, n_id_2 = chain % 3, channel = chain / 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = blockIdx.x * 4 + w;
+  const int idx = blockIdx.y * 4 + w;
   const int count = a.rec_count[chain];
-  if ((int)blockIdx.x * 4 >= count) return; // whole block beyond this chain's records
+  if ((int)blockIdx.y * 4 >= count) return; // whole block beyond this chain's records
   load_lds_tables(ltab, a.tab, n_id_2);
   __syncthreads();
   if (idx >= count) return;
@@ -1245,7 +1245,8 @@ hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream)
       c.tab = L.tab;
       c.n_chains = L.n_channels * 3;
       if (L.rec_cap > 0) {
-        const dim3 per_record((unsigned)((L.rec_cap + 3) / 4), (unsigned)(L.n_channels * 3));
+        if ((L.rec_cap + 3) / 4 > 65535) return hipErrorInvalidValue; // (a capture of > 37 minutes per run)
+        const dim3 per_record((unsigned)(L.n_channels * 3), (unsigned)((L.rec_cap + 3) / 4));
         hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, stream, c);
         hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)c.n_chains), dim3(64), 0, stream, c);
         hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, stream, q);
