@@ -298,7 +298,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
       unsigned long long t0_ = profp ? __builtin_amdgcn_s_memtime() : 0;
       SearchResult r;
       if constexpr (kBulk) {
-        // lag tid + 512 i.  Interior lags 127..9599 = position-independent metric P[pos + lag]; the 253
+        // lag tid + NT i.  Interior lags 127..9599 = position-independent metric P[pos + lag]; the 253
         // edge lags come from lt_edge_kernel's table while the chain is on the 9600-sample grid and are
         // recomputed from the window's first and last 128 samples once it has re-aligned.
         float met[NL];
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
 // P[root][channel][p] = | sum_m h_root[m] x[channel][p - m] |^2 for every sample position p (x[<0] = 0):
 // the position-independent part of srslte_pss_find_pss's convolution, for all three roots from ONE
 // forward FFT per 1024-sample overlap-save block (897 new positions per block).  One wave per block
-// (csrc/lt_fft.h, full-wave form: 16 values per lane), 8 blocks per workgroup; inputs come straight
+// (csrc/lt_fft.h, full-wave form: 16 values per lane), one persistent workgroup of 12 waves per CU; inputs come straight
 // from HBM (16 x 512-byte rows per block), outputs go back as 3 x 897 floats.  Algorithmic bytes: 8 B read + 12 B written per sample.
 struct MetricArgs {
   const v2f *iq;   // [n_channels][ch_stride]
