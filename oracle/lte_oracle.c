@@ -571,6 +571,7 @@ int64_t orc_chain_run(int channel, int n_id_2, const orc_cf *x, int64_t n,
   float psr_data[ORC_MOVING_AVG_SZ] = {0}, cfo_data[ORC_MOVING_AVG_SZ] = {0};
   size_t psr_i = 0, cfo_i = 0;
   float psr = 0.f, psr_max = 0.f;
+  (void)psr_data; /* the ring is kept (lib/pss_impl.cc:166) but only mean_psr(), which nothing here calls, reads it */
   int peak_pos = 0;
 
   orc_cf *win = (orc_cf *)malloc(sizeof(orc_cf) * HF);
