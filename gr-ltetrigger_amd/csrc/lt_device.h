@@ -65,10 +65,14 @@ struct ChainState {
   float psr_max;        // d_psr_max
   float m_norm_avg;     // srslte_sync_t::M_norm_avg
   float m_ext_avg;      // srslte_sync_t::M_ext_avg
-  float pad0;
+  int32_t ema_sel;      // which of avg[2] is current (the grid scan writes the other one, lt_scan_kernels.h)
+  int32_t scan_live;    // this run: the chain is (still) served by the grid scan
+  int32_t scan_job;     // this run: its job, -1 = none
+  int32_t scan_done;    // this run: windows of the job the resolver has turned into records
+  int32_t scan_seg0;    // this run: first window of the scan segment avg[ema_sel] is the state before
   float psr_data[kMovingAvgSz];
   float cfo_data[kMovingAvgSz];
-  float avg[kConvLen];  // srslte_pss_t::conv_output_avg (lags >= 9726 stay 0)
+  float avg[2][kConvLen]; // srslte_pss_t::conv_output_avg (lags >= 9726 stay 0), natural lag order
 };
 
 // LDS scratch for block reductions and the sss stage.

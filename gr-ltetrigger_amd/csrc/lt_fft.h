@@ -20,6 +20,15 @@
 #define LT_HD inline
 #endif
 
+// Scheduling fence (device code only): keeps the compiler from hoisting every LDS twiddle read of a stage
+// above the first multiply, which costs 60 registers and, under the 168-register budget of three waves per
+// SIMD, turns into scratch spills.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LT_FFT_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define LT_FFT_FENCE ((void)0)
+#endif
+
 namespace lt {
 namespace fft {
 
@@ -183,10 +192,14 @@ constexpr int kScratchW = 16 * kRowA;      // c32 entries of scratch per transfo
 template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const c32x2 *tw1, c32 *e)
 {
   fft16<1, kInv>(v);
+  LT_FFT_FENCE;
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) {
+#ifndef LT_ABL_NO_TW
     if (k1) v[k1] = cmul2<kInv>(v[k1], tw1[k1 * 64 + l]);
+#endif
     e[k1 * kRowA + l] = v[k1];
+    if ((k1 & 3) == 3) LT_FFT_FENCE;
   }
 }
 template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32x2 *tw2, const c32 *e1, c32 *e2)
@@ -194,11 +207,16 @@ template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32x2 *t
   const int k1 = l >> 2, c = l & 3;
 #pragma unroll
   for (int s = 0; s < 16; ++s) v[s] = e1[k1 * kRowA + c + 4 * s];
+  LT_FFT_FENCE;
   fft16<1, kInv>(v);
+  LT_FFT_FENCE;
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
+#ifndef LT_ABL_NO_TW
     if (t) v[t] = cmul2<kInv>(v[t], tw2[t * 4 + c]);
+#endif
     e2[c * kRowC + k1 + 16 * t] = v[t];
+    if ((t & 3) == 3) LT_FFT_FENCE;
   }
 }
 template <bool kInv> LT_HD void fft1024w_stageC(int l, c32 v[16], const c32 *e2)

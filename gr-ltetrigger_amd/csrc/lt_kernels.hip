@@ -99,7 +99,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   // ---- load state
   float ema[NL];
 #pragma unroll
-  for (int t = 0; t < NL; ++t) ema[t] = st->avg[kBulk ? tid + t * NT : tid * NL + t];
+  for (int t = 0; t < NL; ++t) ema[t] = st->avg[0][kBulk ? tid + t * NT : tid * NL + t];
   for (int i = tid; i < kMovingAvgSz; i += NT) {
     psr_data[i] = st->psr_data[i];
     cfo_data[i] = st->cfo_data[i];
@@ -558,7 +558,7 @@ template <bool kDiag, bool kBulk> __global__ __launch_bounds__(kBulk ? kThreadsR
   // ---- store state
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < NL; ++t) st->avg[kBulk ? tid + t * NT : tid * NL + t] = ema[t];
+  for (int t = 0; t < NL; ++t) st->avg[0][kBulk ? tid + t * NT : tid * NL + t] = ema[t];
   for (int i = tid; i < kMovingAvgSz; i += NT) {
     st->psr_data[i] = psr_data[i];
     st->cfo_data[i] = cfo_data[i];

@@ -1,0 +1,351 @@
+// Strip-wise form of srslte_pss_find_pss (call site lib/pss_impl.cc:165-167) for gfx950.
+//
+// One search window = 9600 samples between zero pads = 9726 lags of the 128-tap matched filter.  The lags
+// are cut into 12 strips of 811; strip s is one 1024-point overlap-save block whose 896 usable outputs are
+// the lags c0 .. c0 + 895, c0 = 811 s - 41 (41 lags of halo on the left, 44 on the right), so the window's
+// head and tail lags -- whose convolution sums run into the zero pads -- need no special case: a block's
+// samples outside [0, 9600) of the window are zero, exactly srsLTE's zero-padded input.
+//
+//   block element q = lane + 64 R (R = 0..15)  <->  window sample 811 s - 169 + q
+//   lag c0 + lane + 64 r (r = 0..13)            <->  output element q with R = r + 2
+//
+// A wave owns a strip: its 14 registers per lane hold the exponential average (alpha = 0.2) of those 896
+// lags across windows, so the average never leaves the register file between windows.  The strip reduces
+// itself to a StripPartial (its maximum over the lags it owns, the main lobe around it walked inside a
+// 64-lag neighbourhood, the maximum over its lags outside that lobe) and resolve_window() combines the 12
+// partials of a window into peak position, peak value and peak-to-side-lobe ratio.  tests/strip_model.py is
+// the numpy twin of strip_resolve() + resolve_window(); tests/test_strip_model.py checks the decomposition
+// against oracle/lte_oracle.c:295-316.
+#pragma once
+#include "lt_device.h"
+
+namespace lt {
+
+constexpr int kStrips = 12;
+constexpr int kStripPitch = 811;   // lags owned by a strip (12 * 811 = 9732 >= 9726)
+constexpr int kStripHalo = 41;     // computed lags in front of the owned ones
+constexpr int kStripRegs = 14;     // computed lags per lane
+constexpr int kStripIn0 = -(kStripHalo + kSymbolSz); // window sample of block element 0, relative to 811 s
+static_assert(kStrips * kStripPitch >= kNLags, "strips must cover every lag");
+static_assert(kStripHalo >= 32 && 64 * kStripRegs - kStripHalo - kStripPitch >= 32, "halo must hold the lobe walk");
+
+constexpr uint32_t kPartWide = 1u;  // lobe not closed inside the strip's 64-lag neighbourhood: exact path needed
+
+// What a strip tells the resolver about one window (32 bytes, one per (chain, window, strip)).
+struct StripPartial {
+  float m1;       // maximum of the average over the lags the strip owns
+  int32_t p1;     // its lag (first one in lag order)
+  float s;        // maximum over the owned lags outside [lb, ub)
+  int32_t lb;     // main lobe around p1 as srslte_pss_find_pss walks it (window-global stops folded in)
+  int32_t ub;
+  float a0;       // strip 0: average of lag 0 (srslte_vec_max_fi of an empty range returns index 0)
+  uint32_t flags; // kPartWide
+  uint32_t pad;
+};
+static_assert(sizeof(StripPartial) == 32, "StripPartial layout");
+
+__device__ __forceinline__ uint64_t rotr64(uint64_t v, int n) { n &= 63; return n ? (v >> n) | (v << (64 - n)) : v; }
+__device__ __forceinline__ uint64_t rotl64(uint64_t v, int n) { n &= 63; return n ? (v << n) | (v >> (64 - n)) : v; }
+
+// value of lane (l + 1) % 64 / (l - 1) % 64: whole-wave DPP rotates
+__device__ __forceinline__ float wave_next(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, false)); // wave_rol:1
+}
+__device__ __forceinline__ float wave_prev(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // wave_ror:1
+}
+
+// e[r] = average of lag c0 + lane + 64 r.  Wave-uniform result in `out` (every lane holds it).
+__device__ __forceinline__ void strip_resolve(const float (&e)[kStripRegs], int s, int lane, StripPartial &out)
+{
+  const int c0 = kStripPitch * s - kStripHalo;
+  // owned and valid lags: offsets [41, 852) of the computed range, lag < 9726 (strip 11 ends at offset 845)
+  const bool own0 = lane >= kStripHalo;
+  const int own13_end = (s == kStrips - 1) ? (kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13)
+                                           : (kStripHalo + kStripPitch - 64 * 13);
+  const bool own13 = lane < own13_end;
+  float em[kStripRegs];
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) em[r] = e[r];
+  em[0] = own0 ? e[0] : -FLT_MAX;
+  em[13] = own13 ? e[13] : -FLT_MAX;
+  // 1. maximum over the owned lags and where it sits (first in lag order: smallest register, then lane)
+  float m = em[0];
+#pragma unroll
+  for (int r = 1; r < kStripRegs; ++r) m = fmaxf(m, em[r]);
+  const float M1 = wave_max_f(m);
+  int r_p = 0;
+  uint64_t bal = 0;
+#pragma unroll
+  for (int r = kStripRegs - 1; r >= 0; --r) {
+    const uint64_t b = __ballot(em[r] == M1);
+    if (b) {
+      r_p = r;
+      bal = b;
+    }
+  }
+  uint32_t flags = 0;
+  if (!bal) { // only a NaN can do that: outside the contract, but stay in bounds
+    bal = 1ull << kStripHalo;
+    flags = kPartWide;
+  }
+  const int l_p = __builtin_ctzll(bal);
+  const int p1 = c0 + l_p + 64 * r_p;
+  // 2. the lags p1 - 32 .. p1 + 31 as one rotated row: lane L holds offset (L - l_p) wrapped to [-32, 32).
+  // Offsets that fall off this register's 64 lanes come from the register before (l_p < 32) or after it.
+  const int r_b = (l_p < 32) ? r_p - 1 : r_p + 1; // exists whenever a lane needs it (the peak is an owned lag)
+  float rowA = e[0], rowB = e[0];
+#pragma unroll
+  for (int r = 1; r < kStripRegs; ++r) {
+    rowA = (r_p == r) ? e[r] : rowA;
+    rowB = (r_b == r) ? e[r] : rowB;
+  }
+  const bool use_b = (l_p < 32) ? (lane >= l_p + 32) : (lane < l_p - 32);
+  const float row = use_b ? rowB : rowA;
+  const float nxt = wave_next(row), prv = wave_prev(row);
+  const int off = ((lane - l_p + 32) & 63) - 32;
+  const int lag_row = p1 + off;
+  // main-lobe walk (oracle/lte_oracle.c:300-308): right while avg[u+1] <= avg[u] and u < 9727, left while
+  // avg[l-1] <= avg[l] and l > 1; no left walk for a peak at lag <= 2
+  const uint64_t stop_r = rotr64(__ballot(!(nxt <= row) || lag_row >= kConvLen - 1), l_p); // bit j: offset +j
+  const uint64_t stop_l = rotr64(__ballot(!(prv <= row) || lag_row <= 1), l_p);            // bit 64 - j: offset -j
+  const uint64_t mr = stop_r & 0x7FFFFFFEull;         // offsets 1 .. 30
+  const uint64_t ml = stop_l & 0xFFFFFFFE00000000ull; // offsets -31 .. -1
+  int j_r = 1, j_l = 1;
+  if (mr) j_r = __builtin_ctzll(mr);
+  else flags |= kPartWide;
+  if (p1 <= 2) j_l = p1; // pl_lb = 0
+  else if (ml) j_l = 1 + __builtin_clzll(ml);
+  else flags |= kPartWide;
+  const int lb = p1 - j_l, ub = p1 + j_r;
+  // 3. maximum over the owned lags outside [lb, ub).  The lobe's lags sit in registers r_p / r_b of the
+  // lanes at offsets [-j_l, j_r); every other register of those lanes, and everything in the other lanes, counts.
+  const uint64_t lobe_rot = ((1ull << j_r) - 1ull) | (j_l ? (~0ull << (64 - j_l)) : 0ull);
+  const uint64_t lobe = rotl64(lobe_rot, l_p);
+  const bool in_lobe = (lobe >> lane) & 1ull;
+  const float rowA_out = (in_lobe && !use_b) ? -FLT_MAX : ((r_p == 0) ? em[0] : (r_p == 13) ? em[13] : rowA);
+  const float rowB_out = (in_lobe && use_b) ? -FLT_MAX : ((r_b == 0) ? em[0] : (r_b == 13) ? em[13] : rowB);
+  float so = fmaxf(rowA_out, (r_b >= 0 && r_b < kStripRegs) ? rowB_out : -FLT_MAX);
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) so = fmaxf(so, (r == r_p || r == r_b) ? -FLT_MAX : em[r]);
+  const float S = wave_max_f(so);
+  out.m1 = M1;
+  out.p1 = p1;
+  out.s = S;
+  out.lb = lb;
+  out.ub = ub;
+  out.a0 = (s == 0) ? rlane(e[0], kStripHalo) : 0.f;
+  out.flags = flags;
+  out.pad = 0;
+}
+
+struct WindowResult {
+  int peak_pos;
+  float peak_value;
+  float psr;
+  bool exact; // false: a lobe did not close inside its strip's neighbourhood -- the window needs the exact path
+};
+
+// The 12 partials of one window -> srslte_pss_find_pss's results.  Plain scalar code (one lane per window in
+// the resolver kernel, wave-uniform in the chain kernel).  `parts` may be global or LDS memory.
+template <typename Ptr> __device__ __forceinline__ WindowResult resolve_window(Ptr parts)
+{
+  int best = 0;
+  float bm = parts[0].m1;
+#pragma unroll 1
+  for (int s = 1; s < kStrips; ++s) { // strips ascend in lag: strict > keeps the first maximum
+    const float v = parts[s].m1;
+    if (v > bm) {
+      bm = v;
+      best = s;
+    }
+  }
+  WindowResult w;
+  const uint32_t bflags = parts[best].flags;
+  w.exact = !(bflags & kPartWide);
+  w.peak_value = bm;
+  w.peak_pos = (bm > -FLT_MAX) ? parts[best].p1 : 0; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
+  const int lb = parts[best].lb, ub = parts[best].ub;
+  float out = parts[best].s;
+#pragma unroll 1
+  for (int s = 0; s < kStrips; ++s) {
+    if (s == best) continue;
+    const int p = parts[s].p1;
+    const bool inside = p >= lb && p < ub; // that strip's maximum lies on the slope of this lobe
+    if (inside && (parts[s].flags & kPartWide)) w.exact = false;
+    const float v = inside ? parts[s].s : parts[s].m1;
+    if (v > out) out = v;
+  }
+  // empty ranges stand for their first element: the left one is empty exactly when the peak sits at lag <= 2,
+  // the right one when the lobe reaches lag 9726 (avg[9726..9727] = 0)
+  const float sl = (w.peak_pos <= 2) ? parts[0].a0 : out;
+  const float sr = (ub >= kNLags) ? 0.f : out;
+  const float side = sl > sr ? sl : sr;
+  w.psr = w.peak_value / side;
+  return w;
+}
+
+// ---- the strip's matched filter
+
+// window-relative index of block element q of strip s
+__device__ __forceinline__ int strip_sample(int s, int q) { return kStripPitch * s + kStripIn0 + q; }
+
+// A capture as the kernels see it: the chunk handed to this run plus what the previous chunks left behind.
+//   absolute sample a >= t0          -> iq[a - t0]            (a < t0 + n)
+//   t0 - hist_len <= a < t0          -> hist[a - t0 + hist_len]
+//   a < t0 - hist_len (or a < 0)     -> 0   ("zero history at stream start", set_history lib/pss_impl.cc:81)
+struct Capture {
+  const v2f *iq;    // this channel's chunk
+  const v2f *hist;  // this channel's history (may be null when hist_len == 0)
+  int64_t t0;       // absolute index of iq[0]
+  int64_t n;        // samples in the chunk
+  int64_t hist_len; // samples of history kept in front of t0
+};
+// Branch-free (the loads of a block must all be in flight together): out-of-range samples read the chunk's
+// first sample and are zeroed afterwards.
+__device__ __forceinline__ v2f ld_abs(const Capture &c, int64_t a)
+{
+  const int64_t i = a - c.t0, h = i + c.hist_len;
+  const bool in_chunk = i >= 0 && i < c.n, in_hist = i < 0 && h >= 0;
+  const v2f *p = in_hist ? c.hist + h : c.iq + (in_chunk ? i : 0);
+  const v2f v = *p;
+  v2f z = {0.f, 0.f};
+  return (in_chunk || in_hist) ? v : z;
+}
+
+// the 1024 samples of strip s of the window starting at absolute position w0 (zero outside the window)
+__device__ __forceinline__ void strip_load(const Capture &c, int64_t w0, int s, int lane, fft::c32 (&x)[16])
+{
+  const int i0 = strip_sample(s, lane);
+  if (w0 >= c.t0 && w0 + kHalfFrame <= c.t0 + c.n) { // window inside the chunk (always, but for the first ones of a run)
+    const v2f *__restrict__ p = c.iq + (w0 - c.t0);
+    if (s > 0 && s < kStrips - 1) {
+#pragma unroll
+      for (int R = 0; R < 16; ++R) x[R] = __builtin_nontemporal_load(&p[i0 + 64 * R]);
+    } else { // first / last strip: the block reaches into the window's zero pads
+#pragma unroll
+      for (int R = 0; R < 16; ++R) {
+        const int i = i0 + 64 * R;
+        const bool ok = i >= 0 && i < kHalfFrame;
+        const v2f v = __builtin_nontemporal_load(&p[ok ? i : 0]);
+        v2f z = {0.f, 0.f};
+        x[R] = ok ? v : z;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int R = 0; R < 16; ++R) {
+      const int i = i0 + 64 * R;
+      const bool ok = i >= 0 && i < kHalfFrame;
+      const v2f v = ld_abs(c, w0 + (ok ? i : 0));
+      v2f z = {0.f, 0.f};
+      x[R] = ok ? v : z;
+    }
+  }
+}
+
+// in-place 1024-point transform of the wave's block (element lane + 64 R in x[R]); e = the wave's exchange area
+template <bool kInv> __device__ __forceinline__ void strip_fft(int lane, fft::c32 (&x)[16], const fft::c32x2 *tw1,
+                                                                const fft::c32x2 *tw2, fft::c32 *e)
+{
+  fft::fft1024w_stageA<kInv>(lane, x, tw1, e);
+  __builtin_amdgcn_sched_barrier(0);
+  fft::fft1024w_stageB<kInv>(lane, x, tw2, e, e);
+  __builtin_amdgcn_sched_barrier(0);
+  fft::fft1024w_stageC<kInv>(lane, x, e);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// the first two stages of the forward transform: the block is left in the exchange area e, ready for stage C
+__device__ __forceinline__ void strip_fft_ab(int lane, fft::c32 (&x)[16], const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e)
+{
+  fft::fft1024w_stageA<false>(lane, x, tw1, e);
+  __builtin_amdgcn_sched_barrier(0);
+  fft::fft1024w_stageB<false>(lane, x, tw2, e, e);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One window of one root of one strip: spectrum of the block (X) times the filter spectrum, back to the lag
+// domain, |.|^2 and the exponential average with its three roundings (srsLTE's three vector passes,
+// oracle/lte_oracle.c:289-293).  Lags outside [0, 9726) stay 0.
+__device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f *spec,
+                                                  const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e,
+                                                  float (&ema)[kStripRegs])
+{
+#pragma unroll
+#ifndef LT_ABL_NO_SPEC
+  for (int R = 0; R < 16; ++R) v[R] = fft::cmul<false>(v[R], spec[lane + 64 * R]);
+#endif
+#ifndef LT_ABL_NO_IFFT
+  strip_fft<true>(lane, v, tw1, tw2, e);
+#endif
+  const bool valid0 = !(s == 0 && lane < kStripHalo);
+  const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13; // strip 11: lanes below hold lags < 9726
+  const bool valid13 = !(s == kStrips - 1 && lane >= end13);
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) {
+    const fft::c32 y = v[r + 2];
+    const float met = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
+    float ne = __fadd_rn(__fmul_rn(met, 0.2f), __fmul_rn(ema[r], 1.0f - 0.2f));
+    if (r == 0) ne = valid0 ? ne : 0.f;
+    if (r == kStripRegs - 1) ne = valid13 ? ne : 0.f;
+    ema[r] = ne;
+  }
+}
+
+#ifdef LT_SCAN_PROF
+// diagnostics build: the same with shader-clock stamps between the stages (tools/scan_bench.hip)
+__device__ __forceinline__ void strip_root_update_prof(int s, int lane, fft::c32 (&v)[16], const v2f *spec,
+                                                       const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e,
+                                                       float (&ema)[kStripRegs], unsigned long long (&pr)[8], unsigned long long &tp)
+{
+#define LT_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+  for (int R = 0; R < 16; ++R) v[R] = fft::cmul<false>(v[R], spec[lane + 64 * R]);
+  LT_PS(2) // filter spectrum
+  fft::fft1024w_stageA<true>(lane, v, tw1, e);
+  LT_PS(3)
+  fft::fft1024w_stageB<true>(lane, v, tw2, e, e);
+  LT_PS(4)
+  fft::fft1024w_stageC<true>(lane, v, e);
+  LT_PS(5)
+  const bool valid0 = !(s == 0 && lane < kStripHalo);
+  const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13;
+  const bool valid13 = !(s == kStrips - 1 && lane >= end13);
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) {
+    const fft::c32 y = v[r + 2];
+    const float met = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
+    float ne = __fadd_rn(__fmul_rn(met, 0.2f), __fmul_rn(ema[r], 1.0f - 0.2f));
+    if (r == 0) ne = valid0 ? ne : 0.f;
+    if (r == kStripRegs - 1) ne = valid13 ? ne : 0.f;
+    ema[r] = ne;
+  }
+  LT_PS(6)
+#undef LT_PS
+}
+#endif
+
+// the strip's slice of conv_output_avg (natural lag order in HBM) <-> registers
+__device__ __forceinline__ void strip_ema_load(const float *__restrict__ avg, int s, int lane, float (&ema)[kStripRegs])
+{
+  const int c0 = kStripPitch * s - kStripHalo;
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) {
+    const int lag = c0 + lane + 64 * r;
+    ema[r] = (lag >= 0 && lag < kNLags) ? avg[lag] : 0.f;
+  }
+}
+__device__ __forceinline__ void strip_ema_store(float *__restrict__ avg, int s, int lane, const float (&ema)[kStripRegs])
+{
+  const int c0 = kStripPitch * s - kStripHalo;
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) {
+    const int o = lane + 64 * r, lag = c0 + o;
+    if (o >= kStripHalo && o < kStripHalo + kStripPitch && lag < kConvLen) avg[lag] = (lag < kNLags) ? ema[r] : 0.f;
+  }
+}
+
+} // namespace lt

@@ -1,0 +1,191 @@
+// Grid scan: srslte_pss_find_pss (lib/pss_impl.cc:165-167) of every idle chain, window after window, with
+// the exponential average held in registers and nothing but 32-byte partial results per (window, strip)
+// written back.  See lt_scan.h for the strip geometry.
+//
+// A chain is idle when it is neither tracking nor building a score: every general_work call then searches its
+// 9600-sample window, misses and moves on by exactly 9600 samples (lib/pss_impl.cc:163-182, 217), so the
+// windows a chain will search are known in advance as long as it keeps missing.  That is what nearly all
+// chains do nearly all the time, and the search is where the arithmetic is.  The scan runs those windows
+// for all such chains at once, speculatively: lt_resolve_kernel then walks each chain's windows in call order,
+// writes the records of the misses and stops at the first window that fires (PSR over the threshold) or that
+// the strips could not resolve; from that window on the chain belongs to the per-chain kernel (lt_chain.h),
+// which executes general_work call by call.
+//
+// Work decomposition.  A *job* is a capture channel together with the idle chains (roots) of it that share
+// one window alignment -- normally all three.  A job's 12 strips go to four workgroups of three *groups*;
+// a group is four waves that own one strip for good: a forward wave, which fetches the strip's 1024 samples of
+// every window and transforms them once, and one wave per root, which multiplies that spectrum by its root's
+// filter spectrum, transforms back and keeps its root's average.  The hand-over costs no LDS of its own: the
+// forward wave stops after the second exchange of its transform, and each root wave runs the last radix-4 stage
+// itself, straight out of the forward wave's exchange area.
+//   workgroup = 12 waves = 3 per SIMD; LDS: 12 exchange areas (102 KB) + filter spectra (24 KB) + twiddles (17 KB)
+#pragma once
+#include "lt_scan.h"
+
+// Ordering of the LDS hand-over.  A wave's LDS instructions execute in program order, so a counter written
+// after the data (or read before it) needs no s_waitcnt -- only the compiler must keep the order.  A
+// workgroup-scope fence would also wait for the wave's global loads and stores (vmcnt(0)): the forward wave's
+// prefetch of the next windows and the root waves' partial-result stores, i.e. a full memory latency per window.
+#define LT_LDS_ORDER __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+
+#ifndef LT_SCAN_STAGGER
+#define LT_SCAN_STAGGER 0 // s_sleep units (64 clocks) by which group g starts later than group g - 1
+#endif
+
+namespace lt {
+
+// One per (channel, alignment): built by lt_plan_kernel from the chain states.
+struct ScanJob {
+  int64_t pos0;      // absolute position of the job's window 0
+  int32_t channel;
+  int32_t n_windows; // windows the idle chains may search in this run
+  int32_t roots;     // bit r: chain (channel, N_id_2 = r) is part of the job
+  int32_t rec0[3];   // per root: record index of window 0
+};
+
+constexpr int kScanWaves = 12;
+constexpr int kScanThreads = 64 * kScanWaves;
+constexpr int kScanGroups = 3;              // strips per workgroup
+constexpr int kScanWgPerJob = kStrips / kScanGroups;
+
+struct ScanArgs {
+  const v2f *iq;       // [n_channels][ch_stride]
+  int64_t ch_stride;
+  const v2f *hist;     // [n_channels][hist_stride] or null
+  int64_t hist_stride;
+  int64_t t0, n, hist_len;
+  const ScanJob *jobs;
+  const int *n_jobs;
+  ChainState *state;   // [n_channels * 3]
+  StripPartial *parts; // [n_channels * 3][parts_windows][12]
+  int64_t parts_windows;
+  int w_begin, w_end;  // this segment: windows [w_begin, w_end) of every job
+  const DeviceTables *tab;
+  unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
+};
+
+__global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
+{
+  __shared__ v2f E[kScanWaves * fft::kScratchW]; // one exchange area per wave
+  __shared__ v2f SPEC[3][fft::kN];               // filter spectra / 1024, natural order
+  __shared__ fft::c32x2 TW1[16 * 64];
+  __shared__ fft::c32x2 TW2[16 * 4];
+  __shared__ int sync_ready[kScanGroups], sync_taken[kScanGroups];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroups b, b + 8, b + 16, b + 24 (one XCD under round-robin dispatch) share a job: its strips overlap
+  // by 213 samples, so the second read of those comes from that XCD's L2
+  const int b = blockIdx.x;
+  const int slot = b >> 3;
+  const int job_i = (slot / kScanWgPerJob) * 8 + (b & 7);
+  const int quarter = slot % kScanWgPerJob;
+  if (job_i >= *a.n_jobs) return;
+  const ScanJob job = a.jobs[job_i];
+  const int w_end = a.w_end < job.n_windows ? a.w_end : job.n_windows;
+  if (a.w_begin >= w_end) return;
+  // group g = w % 3 owns strip 3 quarter + g; role w / 3: 0 = forward, 1..3 = root 0..2 (the three forward
+  // waves land on three different SIMDs)
+  const int g = w % kScanGroups, role = w / kScanGroups;
+  const int strip = quarter * kScanGroups + g;
+  const int root = role - 1;
+  // a root leaves the job for good once the resolver has seen it fire (scan_live cleared)
+  int live_mask = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if ((job.roots >> r) & 1)
+      if (a.state[job.channel * 3 + r].scan_live) live_mask |= 1 << r;
+  if (!live_mask) return;
+  const bool active = role == 0 || ((live_mask >> root) & 1);
+
+  for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw1[i]);
+  if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw2[tid]);
+  for (int i = tid; i < 3 * fft::kN; i += kScanThreads) {
+    const cf32 h = a.tab->pss_spec[i >> 10][i & 1023];
+    SPEC[i >> 10][i & 1023] = v2f{h.re, h.im};
+  }
+  if (tid < kScanGroups) sync_ready[tid] = sync_taken[tid] = 0;
+  __syncthreads(); // tables in place: the only workgroup barrier
+  fft::c32 *e = E + w * fft::kScratchW;
+  const fft::c32 *e_fwd = E + g * fft::kScratchW; // the group's forward wave is wave g
+
+  Capture cap;
+  cap.iq = a.iq + (int64_t)job.channel * a.ch_stride;
+  cap.hist = a.hist ? a.hist + (int64_t)job.channel * a.hist_stride : nullptr;
+  cap.t0 = a.t0;
+  cap.n = a.n;
+  cap.hist_len = a.hist ? a.hist_len : 0;
+
+  // The two roles run separate loops, so that each gets a register allocation of its own: the forward wave
+  // carries two blocks of samples, a root wave one block and its average.  Hand-over per group through two LDS
+  // counters (no workgroup barrier after the table load: the three groups of a workgroup drift apart, which is
+  // wanted -- every SIMD holds one wave of each group, and waves in different phases of the transform keep
+  // both the vector unit and the LDS busy):
+  //   ready[g] = windows whose first two transform stages sit in the forward wave's exchange area (1 at a time)
+  //   taken[g] = sum over the root waves of the windows they have read from it
+  const int n_roots = __builtin_popcount(live_mask);
+  const int n_w = w_end - a.w_begin;
+#if LT_SCAN_STAGGER
+  for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(LT_SCAN_STAGGER);
+#endif
+  if (role == 0) {
+    fft::c32 x[16];  // the block being transformed
+    fft::c32 xn[16]; // the next window's block, in flight
+    strip_load(cap, job.pos0 + (int64_t)a.w_begin * kHalfFrame, strip, lane, x);
+    if (n_w > 1) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + 1) * kHalfFrame, strip, lane, xn);
+    for (int k = 0; k < n_w; ++k) {
+      // the root waves have taken window k - 1: the exchange area is free
+      while (__hip_atomic_load(&sync_taken[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_roots * k) __builtin_amdgcn_s_sleep(1);
+      LT_LDS_ORDER;
+      strip_fft_ab(lane, x, TW1, TW2, e);
+      LT_LDS_ORDER;
+      if (lane == 0) __hip_atomic_store(&sync_ready[g], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int R = 0; R < 16; ++R) x[R] = xn[R];
+      if (k + 2 < n_w) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + k + 2) * kHalfFrame, strip, lane, xn);
+    }
+  } else if (active) {
+#ifdef LT_ROOT_PRIO
+    __builtin_amdgcn_s_setprio(LT_ROOT_PRIO);
+#endif
+    fft::c32 x[16]; // spectrum, then lags
+    float ema[kStripRegs];
+    ChainState *st = a.state + job.channel * 3 + root;
+    strip_ema_load(st->avg[st->ema_sel], strip, lane, ema);
+    StripPartial *parts = a.parts + ((int64_t)(job.channel * 3 + root) * a.parts_windows + a.w_begin) * kStrips + strip;
+#ifdef LT_SCAN_PROF
+    unsigned long long pr[8] = {0}, tp = __builtin_amdgcn_s_memtime();
+#define LT_PSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; }
+#else
+#define LT_PSTAMP(i)
+#endif
+    for (int k = 0; k < n_w; ++k) {
+      while (__hip_atomic_load(&sync_ready[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+      LT_LDS_ORDER;
+      LT_PSTAMP(0) // waiting for the forward wave
+      fft::fft1024w_stageC<false>(lane, x, e_fwd); // x = the block's spectrum
+      LT_LDS_ORDER;
+      if (lane == 0) __hip_atomic_fetch_add(&sync_taken[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      LT_PSTAMP(1) // last forward stage
+#ifdef LT_SCAN_PROF
+      strip_root_update_prof(strip, lane, x, SPEC[root], TW1, TW2, e, ema, pr, tp);
+#else
+      strip_root_update(strip, lane, x, SPEC[root], TW1, TW2, e, ema);
+#endif
+      StripPartial p;
+#ifndef LT_ABL_NO_RESOLVE
+      strip_resolve(ema, strip, lane, p);
+#else
+      p.m1 = ema[3]; p.p1 = 0; p.s = ema[5]; p.lb = p.ub = 0; p.a0 = 0.f; p.flags = 0; p.pad = 0;
+#endif
+      if (lane == 0) parts[(int64_t)k * kStrips] = p;
+      LT_PSTAMP(7) // resolve + store
+    }
+#ifdef LT_SCAN_PROF
+    if (a.prof && blockIdx.x == 8 && w == 7 && lane == 0)
+      for (int i = 0; i < 8; ++i) a.prof[i] = pr[i];
+#endif
+    strip_ema_store(st->avg[st->ema_sel ^ 1], strip, lane, ema);
+  }
+}
+
+} // namespace lt

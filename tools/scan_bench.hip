@@ -1,0 +1,115 @@
+// Stand-alone timing of lt_scan_kernel (csrc/lt_scan_kernels.h) on random data: 64 jobs x 200 windows, all
+// three roots live.  Also checks the DPP whole-wave rotates the strip resolver relies on.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o build/scan_bench tools/scan_bench.hip csrc/lt_tables.cpp
+#include "../gr-ltetrigger_amd/csrc/lt_scan_kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace lt;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+__global__ void k_rot(float *out)
+{
+  const float v = (float)threadIdx.x;
+  out[threadIdx.x] = wave_next(v);
+  out[64 + threadIdx.x] = wave_prev(v);
+}
+
+int main(int argc, char **argv)
+{
+  const int n_ch = argc > 1 ? atoi(argv[1]) : 64;
+  const int n_win = argc > 2 ? atoi(argv[2]) : 200;
+  const int64_t n = (int64_t)n_win * kHalfFrame;
+  {
+    float *d;
+    CK(hipMalloc(&d, 128 * sizeof(float)));
+    hipLaunchKernelGGL(k_rot, dim3(1), dim3(64), 0, 0, d);
+    float h[128];
+    CK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    printf("wave_next: lane0=%g lane1=%g lane63=%g   wave_prev: lane0=%g lane1=%g lane63=%g\n", h[0], h[1], h[63], h[64], h[65], h[127]);
+    bool ok = true;
+    for (int l = 0; l < 64; ++l) ok = ok && h[l] == (float)((l + 1) & 63) && h[64 + l] == (float)((l + 63) & 63);
+    printf("whole-wave rotates %s\n", ok ? "OK" : "WRONG");
+  }
+  DeviceTables *htab = new DeviceTables, *dtab;
+  build_device_tables(htab);
+  CK(hipMalloc(&dtab, sizeof(DeviceTables)));
+  CK(hipMemcpy(dtab, htab, sizeof(DeviceTables), hipMemcpyHostToDevice));
+  std::vector<float> hiq((size_t)n_ch * n * 2);
+  unsigned s = 12345;
+  for (auto &v : hiq) {
+    s = s * 1664525u + 1013904223u;
+    v = ((int)(s >> 8) & 0xFFFF) / 32768.0f - 1.0f;
+  }
+  v2f *diq;
+  CK(hipMalloc(&diq, hiq.size() * sizeof(float)));
+  CK(hipMemcpy(diq, hiq.data(), hiq.size() * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<ScanJob> jobs(n_ch);
+  for (int c = 0; c < n_ch; ++c) {
+    jobs[c].pos0 = 0;
+    jobs[c].channel = c;
+    jobs[c].n_windows = n_win;
+    jobs[c].roots = 7;
+    jobs[c].rec0[0] = jobs[c].rec0[1] = jobs[c].rec0[2] = 0;
+  }
+  ScanJob *djobs;
+  int *dnj;
+  CK(hipMalloc(&djobs, sizeof(ScanJob) * n_ch));
+  CK(hipMemcpy(djobs, jobs.data(), sizeof(ScanJob) * n_ch, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dnj, sizeof(int)));
+  CK(hipMemcpy(dnj, &n_ch, sizeof(int), hipMemcpyHostToDevice));
+  ChainState *dst;
+  CK(hipMalloc(&dst, sizeof(ChainState) * n_ch * 3));
+  CK(hipMemset(dst, 0, sizeof(ChainState) * n_ch * 3));
+  {
+    std::vector<ChainState> hst(n_ch * 3);
+    memset(hst.data(), 0, sizeof(ChainState) * hst.size());
+    for (auto &c : hst) c.scan_live = 1;
+    CK(hipMemcpy(dst, hst.data(), sizeof(ChainState) * hst.size(), hipMemcpyHostToDevice));
+  }
+  StripPartial *dparts;
+  CK(hipMalloc(&dparts, sizeof(StripPartial) * (size_t)n_ch * 3 * n_win * kStrips));
+  ScanArgs a;
+  a.iq = diq; a.ch_stride = n; a.hist = nullptr; a.hist_stride = 0; a.t0 = 0; a.n = n; a.hist_len = 0;
+  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.parts_windows = n_win;
+  a.w_begin = 0; a.w_end = n_win; a.tab = dtab;
+  unsigned long long *dprof;
+  CK(hipMalloc(&dprof, 64));
+  CK(hipMemset(dprof, 0, 64));
+  a.prof = dprof;
+  const int grid = ((n_ch + 7) / 8) * 8 * kScanWgPerJob;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int it = 0; it < 4; ++it) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(lt_scan_kernel, dim3(grid), dim3(kScanThreads), 0, 0, a);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("scan %d ch x %d windows: %.3f ms  (%.1f Gsamp/s, %.3f of 8 TB/s at 8 B/sample)\n", n_ch, n_win, ms,
+           (double)n_ch * n / ms * 1e-6, (double)n_ch * n * 8 / (ms * 1e-3) / 8e12);
+  }
+#ifdef LT_SCAN_PROF
+  {
+    unsigned long long hpr[8];
+    CK(hipMemcpy(hpr, dprof, 64, hipMemcpyDeviceToHost));
+    const char *nm[8] = {"wait fwd", "fwd stage C", "x spec", "inv A", "inv B", "inv C", "mag+ema", "resolve"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += hpr[i];
+    for (int i = 0; i < 8; ++i) printf("  %-12s %8.1f clocks/window (%4.1f %%)\n", nm[i], (double)hpr[i] / n_win, 100.0 * hpr[i] / tot);
+    printf("  total %.1f clocks/window (s_memtime ticks)\n", (double)tot / n_win);
+  }
+#endif
+  std::vector<StripPartial> hp((size_t)kStrips * 4);
+  CK(hipMemcpy(hp.data(), dparts, sizeof(StripPartial) * hp.size(), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 24; ++i)
+    printf("part[%d]: m1=%g p1=%d s=%g lb=%d ub=%d a0=%g flags=%u\n", i, hp[i].m1, hp[i].p1, hp[i].s, hp[i].lb, hp[i].ub, hp[i].a0, hp[i].flags);
+  return 0;
+}
