@@ -42,7 +42,8 @@ EXPORTS = [
     "lt_sss_N_id_1", "lt_sync_get_cell_id",
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
-    "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms",
+    "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms", "lt_batch_push",
+    "lt_batch_get_mode", "lt_batch_set_scan_segments",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
 
@@ -108,6 +109,9 @@ def lib():
     L.lt_batch_set_mode.argtypes = [vp, i32]
     L.lt_batch_set_psr_threshold.argtypes = [vp, f32]
     L.lt_batch_run.argtypes = [vp, vp, i32, i64, vp]
+    L.lt_batch_push.argtypes = [vp, vp, i32, i64, i32, vp]
+    L.lt_batch_get_mode.argtypes = [vp]
+    L.lt_batch_set_scan_segments.argtypes = [vp, i32, i32]
     L.lt_batch_collect.argtypes = [vp, vp, i64, vp]
     L.lt_batch_record_capacity.argtypes = [i64]
     L.lt_batch_record_capacity.restype = i64
@@ -279,7 +283,7 @@ def record_capacity(n_samples):
 
 
 class Batch:
-    """Batched pss->sss chains: n_channels x 3 roots, one persistent workgroup each."""
+    """Batched pss->sss chains: n_channels x 3 roots (grid scan of the idle chains + per-chain kernel)."""
 
     def __init__(self, n_channels, max_samples, psr_threshold=4.0, track_after=16, track_every=8,
                  device=0):
@@ -308,8 +312,26 @@ class Batch:
         _check(lib().lt_batch_set_psr_threshold(self._h, t), "lt_batch_set_psr_threshold")
 
     def set_mode(self, mode):
-        """1 = bulk metric kernel + replay kernel (default), 0 = fused per-chain kernel."""
+        """1 = grid scan of the idle chains + per-chain kernel (default), 0 = per-chain kernel only."""
         _check(lib().lt_batch_set_mode(self._h, int(mode)), "lt_batch_set_mode")
+
+    def mode(self):
+        return int(lib().lt_batch_get_mode(self._h))
+
+    def set_scan_segments(self, first, later):
+        _check(lib().lt_batch_set_scan_segments(self._h, int(first), int(later)), "lt_batch_set_scan_segments")
+
+    def push_host(self, iq, end_of_stream=False):
+        """Streaming: iq = the next [n_channels, n] complex64 chunk of the stream."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        if iq.ndim != 2 or iq.shape[0] != self.n_channels:
+            raise ValueError("iq must be [n_channels, n_samples]")
+        _check(lib().lt_batch_push(self._h, iq.ctypes.data_as(C.c_void_p), 0, iq.shape[1], int(bool(end_of_stream)), None),
+               "lt_batch_push")
+
+    def push_device(self, dev_ptr, n_samples, end_of_stream=False, stream=None):
+        _check(lib().lt_batch_push(self._h, C.c_void_p(int(dev_ptr)), 1, int(n_samples), int(bool(end_of_stream)),
+                                   C.c_void_p(int(stream)) if stream else None), "lt_batch_push")
 
     def enable_halfframes(self, max_per_chain):
         _check(lib().lt_batch_enable_halfframes(self._h, int(max_per_chain)), "lt_batch_enable_halfframes")
@@ -345,8 +367,8 @@ class Batch:
         return out[: n.value]
 
     def phase_ms(self, runs_back=0):
-        """(lag-metric kernel, edge-lag kernel, per-chain kernel, per-record post-pass kernels) device
-        times in ms of the run `runs_back` runs ago (the last 8 runs are kept)."""
+        """(plan + grid scan + resolve, 0, per-chain kernel, per-record kernels) device times in ms of the
+        run `runs_back` runs ago (the last 8 runs are kept)."""
         ms = (C.c_float * 4)()
         _check(lib().lt_batch_phase_ms(self._h, int(runs_back), ms), "lt_batch_phase_ms")
         return tuple(float(v) for v in ms)

@@ -3,6 +3,7 @@
 // There is deliberately no CPU implementation of any compute entry point here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -146,20 +147,25 @@ struct lt_batch {
   int rec_cap = 0;
   lt_cf32 *d_hf = nullptr;
   int64_t hf_cap = 0;
-  float *d_metric = nullptr; // bulk + replay mode: [3][n_channels][max_samples]
-  float *d_edge = nullptr;   // bulk + replay mode: [3][n_channels][max_samples / 9600][256]
-  void *d_cp = nullptr;      // bulk + replay mode: [n_channels*3][rec_cap] x 16 B
-  int mode = 1;              // 0 fused chain kernel, 1 bulk metric kernel + replay kernel
-  // events of the last kPhaseRing runs: [run % kPhaseRing][0..4] = start, metric kernel done, edge kernel done,
-  // replay kernel done, end
+  void *d_jobs = nullptr;    // grid scan: ScanJob[n_channels*3]
+  int *d_njobs = nullptr;
+  void *d_parts = nullptr;   // grid scan: StripPartial[n_channels*3][parts_windows][12]
+  int parts_windows = 0;
+  void *d_cp = nullptr;      // per-record CP metrics, [n_channels*3][rec_cap] x 16 B
+  lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
+  int hist_sel = 0;
+  int64_t hist_len = 0;      // valid samples in d_hist[hist_sel] (its tail)
+  int64_t hist_cap = 0;
+  int64_t t0 = 0;            // absolute stream position of the next chunk
+  int mode = 1;              // 0 per-chain kernel only, 1 grid scan + per-chain kernel
+  int seg_first = 2, seg_len = 32;
+  bool pending_reset = false; // lt_batch_reset: applied on the stream of the next run, in front of it
+  // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, scan done, per-chain kernel done, end
   static constexpr int kPhaseRing = 8;
-  hipEvent_t ev[kPhaseRing][5] = {};
-  bool ev_bulk[kPhaseRing] = {};
+  hipEvent_t ev[kPhaseRing][4] = {};
   uint64_t n_runs = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr; // = ev[last run][0], [4]
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; // = ev[last run][0], [3]
   bool ran = false;
-  int ablate = 0;
-  unsigned long long *d_prof = nullptr;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
 };
@@ -478,9 +484,15 @@ int lt_sync_get_cell_id(lt_sync *q)
 }
 
 // ------------------------------------------------------------------ batch
+namespace {
+// samples a chain may need in front of a chunk: a call that could not start in the previous chunk lies at most
+// call_reach - 1 samples before its end, and its half-frame may begin one slot earlier still (lib/pss_impl.cc:185-193)
+int64_t history_capacity() { return ((int64_t)lt::call_reach() + LT_SLOT_LEN + 255) / 256 * 256; }
+} // namespace
+
 int64_t lt_batch_record_capacity(int64_t n_samples)
 {
-  return n_samples / (LT_HALF_FRAME_LEN - LT_SLOT_LEN) + 2;
+  return (n_samples + history_capacity()) / (LT_HALF_FRAME_LEN - LT_SLOT_LEN) + 2;
 }
 
 int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samples,
@@ -491,6 +503,8 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   *out = nullptr;
   if (params->track_after <= 0 || params->track_every < 0)
     return fail(LT_ERROR_INVALID_INPUTS, "invalid chain parameters");
+  if (lt_batch_record_capacity(max_samples) > 4 * 65535)
+    return fail(LT_ERROR_INVALID_INPUTS, "max_samples %lld too large for one run (limit: 37 minutes at 1.92 Msps)", (long long)max_samples);
   int rc = use_device(device);
   if (rc) return rc;
   lt_batch *b = new (std::nothrow) lt_batch;
@@ -500,20 +514,30 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   b->max_samples = max_samples;
   b->params = *params;
   b->rec_cap = (int)lt_batch_record_capacity(max_samples);
+  b->hist_cap = history_capacity();
+  b->parts_windows = (int)((max_samples + b->hist_cap) / LT_HALF_FRAME_LEN + 2);
   rc = get_tables(device, &b->tab);
   if (rc) { delete b; return rc; }
+  // Everything a run needs is allocated here, so that no run can fail -- or change its execution strategy -- for
+  // want of memory later.
   const size_t nchains = (size_t)n_channels * 3;
   hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&b->d_state, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_recs, sizeof(lt_record) * nchains * (size_t)b->rec_cap);
   if (e == hipSuccess) e = hipMalloc(&b->d_count, sizeof(int) * nchains);
+  if (e == hipSuccess) e = hipMalloc(&b->d_jobs, (size_t)lt::scan_job_bytes() * nchains);
+  if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::strip_partial_bytes() * nchains * (size_t)b->parts_windows);
+  if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)16 * nchains * (size_t)b->rec_cap);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
   for (int i = 0; i < lt_batch::kPhaseRing && e == hipSuccess; ++i)
-    for (int j = 0; j < 5 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
+    for (int j = 0; j < 4 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
   b->ev0 = b->ev[0][0];
-  b->ev1 = b->ev[0][4];
+  b->ev1 = b->ev[0][3];
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     lt_batch_free(b);
     return fail(LT_ERROR, "lt_batch_create: %s", hipGetErrorString(e));
   }
@@ -526,15 +550,9 @@ void lt_batch_free(lt_batch *b)
   if (!b) return;
   (void)hipSetDevice(b->device);
   if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
-  if (b->d_iq) (void)hipFree(b->d_iq);
-  if (b->d_state) (void)hipFree(b->d_state);
-  if (b->d_recs) (void)hipFree(b->d_recs);
-  if (b->d_count) (void)hipFree(b->d_count);
-  if (b->d_hf) (void)hipFree(b->d_hf);
-  if (b->d_metric) (void)hipFree(b->d_metric);
-  if (b->d_edge) (void)hipFree(b->d_edge);
-  if (b->d_cp) (void)hipFree(b->d_cp);
-  if (b->d_prof) (void)hipFree(b->d_prof);
+  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1]};
+  for (void *p : bufs)
+    if (p) (void)hipFree(p);
   for (auto &set : b->ev)
     for (hipEvent_t e : set)
       if (e) (void)hipEventDestroy(e);
@@ -545,11 +563,11 @@ void lt_batch_free(lt_batch *b)
 int lt_batch_reset(lt_batch *b)
 {
   if (!b) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
-  HIP_TRY(hipSetDevice(b->device));
-  hipStream_t s = b->last_stream ? b->last_stream : b->stream;
-  const size_t nchains = (size_t)b->n_channels * 3;
-  HIP_TRY(hipMemsetAsync(b->d_state, 0, lt::chain_state_bytes() * nchains, s));
-  HIP_TRY(hipMemsetAsync(b->d_count, 0, sizeof(int) * nchains, s));
+  // The state is cleared on the stream of the next run, right in front of it: a memset queued here, on whatever
+  // stream ran last, would not be ordered against a run on another stream.
+  b->pending_reset = true;
+  b->t0 = 0;
+  b->hist_len = 0;
   return LT_OK;
 }
 
@@ -578,7 +596,10 @@ int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain)
   return LT_OK;
 }
 
-int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples, void *hip_stream)
+namespace {
+// One chunk through the path.  restart: the chunk is a capture of its own (positions restart at 0, no history)
+// with the chain state left by the previous run -- lt_batch_run; otherwise it continues the stream -- lt_batch_push.
+int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples, bool restart, int flush, void *hip_stream)
 {
   if (!b || !iq) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
   if (n_samples < 0 || n_samples > b->max_samples)
@@ -586,6 +607,19 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
                 (long long)b->max_samples);
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->stream;
+  // runs on different streams are ordered by the host here: state, records and history are shared
+  if (b->last_stream && b->last_stream != s) HIP_TRY(hipStreamSynchronize(b->last_stream));
+  const size_t nchains = (size_t)b->n_channels * 3;
+  if (b->pending_reset) {
+    HIP_TRY(hipMemsetAsync(b->d_state, 0, lt::chain_state_bytes() * nchains, s));
+    HIP_TRY(hipMemsetAsync(b->d_count, 0, sizeof(int) * nchains, s));
+    b->pending_reset = false;
+  }
+  if (restart) {
+    b->t0 = 0;
+    b->hist_len = 0;
+    HIP_TRY(lt::launch_rebase(b->d_state, (int)nchains, s));
+  }
   const lt_cf32 *d_iq = iq;
   if (!iq_on_device) {
     const size_t bytes = sizeof(lt_cf32) * (size_t)b->n_channels * (size_t)n_samples;
@@ -594,71 +628,65 @@ int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sam
     if (bytes) HIP_TRY(hipMemcpyAsync(b->d_iq, iq, bytes, hipMemcpyHostToDevice, s));
     d_iq = b->d_iq;
   }
-  lt::ChainLaunch L;
-  L.iq = d_iq;
-  L.n_samples = n_samples;
-  L.ch_stride = n_samples;
-  L.n_channels = b->n_channels;
-  L.state = b->d_state;
-  L.recs = b->d_recs;
-  L.rec_cap = b->rec_cap;
-  L.rec_count = b->d_count;
-  L.out_hf = b->d_hf;
-  L.out_cap = (int)b->hf_cap;
-  L.tab = b->tab;
-  L.psr_threshold = b->params.psr_threshold;
-  L.track_after = b->params.track_after;
-  L.track_every = b->params.track_every;
-  L.ablate = b->ablate;
-  {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    L.n_cus = g_ctx[b->device].n_cus > 0 ? g_ctx[b->device].n_cus : 256;
-  }
-  L.prof = b->d_prof;
-  bool bulk = b->mode == 1 && (!(b->ablate & 0xFF) || (b->ablate & 128)); // 128: diagnostics build of the replay kernel
-  const size_t max_windows = (size_t)b->max_samples / 9600 + 1;
-  // the lag-metric kernel numbers its 897-sample blocks with 32 bits
-  if (bulk && (uint64_t)b->n_channels * ((uint64_t)n_samples / 897 + 1) >= (1ull << 31)) bulk = false;
-  if (bulk && (!b->d_metric || !b->d_edge || !b->d_cp)) {
-    // 12 B per sample of HBM for the lag metric: a batch that does not leave room for it runs fused
-    hipError_t e = hipSuccess;
-    if (!b->d_metric) e = hipMalloc(&b->d_metric, sizeof(float) * 3 * (size_t)b->n_channels * (size_t)b->max_samples);
-    if (e == hipSuccess && !b->d_edge)
-      e = hipMalloc(&b->d_edge, sizeof(float) * 3 * (size_t)b->n_channels * max_windows * 256);
-    if (e == hipSuccess && !b->d_cp) e = hipMalloc(&b->d_cp, (size_t)16 * (size_t)b->n_channels * 3 * (size_t)b->rec_cap);
-    if (e != hipSuccess) {
-      (void)hipGetLastError(); // clear the sticky out-of-memory state
-      if (b->d_metric) (void)hipFree(b->d_metric);
-      if (b->d_edge) (void)hipFree(b->d_edge);
-  if (b->d_cp) (void)hipFree(b->d_cp);
-      b->d_metric = b->d_edge = nullptr;
-      b->mode = 0;
-      bulk = false;
-    }
-  }
-  if (bulk) {
-    L.metric = b->d_metric;
-    L.edge = b->d_edge;
-    L.cp_scratch = b->d_cp;
-    L.ev_metric_done = b->ev[b->n_runs % lt_batch::kPhaseRing][1];
-    L.ev_edge_done = b->ev[b->n_runs % lt_batch::kPhaseRing][2];
-    L.ev_replay_done = b->ev[b->n_runs % lt_batch::kPhaseRing][3];
-    L.edge_ch_stride = (int64_t)max_windows * 256;
-    L.edge_root_stride = (int64_t)b->n_channels * L.edge_ch_stride;
-    L.metric_ch_stride = b->max_samples;
-    L.metric_root_stride = (int64_t)b->n_channels * b->max_samples;
-  }
+  lt::RunLaunch R;
+  R.iq = d_iq;
+  R.ch_stride = n_samples;
+  R.t0 = b->t0;
+  R.n = n_samples;
+  R.hist = b->hist_len > 0 ? b->d_hist[b->hist_sel] : nullptr;
+  R.hist_stride = b->hist_cap;
+  R.hist_len = b->hist_len;
+  const int64_t hist_new = restart ? 0 : std::min(b->hist_cap, b->hist_len + n_samples);
+  R.hist_new = hist_new > 0 ? b->d_hist[b->hist_sel ^ 1] : nullptr;
+  R.hist_len_new = hist_new;
+  R.flush = flush;
+  R.n_channels = b->n_channels;
+  R.state = b->d_state;
+  R.recs = b->d_recs;
+  R.rec_cap = b->rec_cap;
+  R.rec_count = b->d_count;
+  R.out_hf = b->d_hf;
+  R.out_cap = (int)b->hf_cap;
+  R.tab = b->tab;
+  R.psr_threshold = b->params.psr_threshold;
+  R.track_after = b->params.track_after;
+  R.track_every = b->params.track_every;
+  R.scan = b->mode;
+  R.jobs = b->d_jobs;
+  R.n_jobs = b->d_njobs;
+  R.parts = b->d_parts;
+  R.parts_windows = b->parts_windows;
+  R.seg_first = b->seg_first;
+  R.seg_len = b->seg_len;
+  R.cp_scratch = b->d_cp;
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
-  b->ev_bulk[slot] = L.metric != nullptr;
+  R.ev_scan_done = b->ev[slot][1];
+  R.ev_chain_done = b->ev[slot][2];
   b->ev0 = b->ev[slot][0];
-  b->ev1 = b->ev[slot][4];
+  b->ev1 = b->ev[slot][3];
   b->n_runs++;
   HIP_TRY(hipEventRecord(b->ev0, s));
-  HIP_TRY(lt::launch_chain(L, s));
+  HIP_TRY(lt::launch_run(R, s));
   HIP_TRY(hipEventRecord(b->ev1, s));
+  if (!restart) {
+    b->t0 += n_samples;
+    if (hist_new > 0) b->hist_sel ^= 1;
+    b->hist_len = hist_new;
+  }
   b->last_stream = s;
   b->ran = true;
   return LT_OK;
+}
+} // namespace
+
+int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples, void *hip_stream)
+{
+  return batch_chunk(b, iq, iq_on_device, n_samples, true, 1, hip_stream);
+}
+
+int lt_batch_push(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples, int end_of_stream, void *hip_stream)
+{
+  return batch_chunk(b, iq, iq_on_device, n_samples, false, end_of_stream ? 1 : 0, hip_stream);
 }
 
 int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4])
@@ -671,16 +699,11 @@ int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4])
   if (rc) return rc;
   const int slot = (int)((b->n_runs - 1 - (uint64_t)runs_back) % lt_batch::kPhaseRing);
   hipEvent_t *e = b->ev[slot];
-  HIP_TRY(hipEventSynchronize(e[4]));
-  ms[0] = ms[1] = ms[3] = 0.f;
-  if (b->ev_bulk[slot]) {
-    HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], e[1], e[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], e[2], e[3]));
-    HIP_TRY(hipEventElapsedTime(&ms[3], e[3], e[4]));
-  } else {
-    HIP_TRY(hipEventElapsedTime(&ms[2], e[0], e[4]));
-  }
+  HIP_TRY(hipEventSynchronize(e[3]));
+  ms[1] = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
+  HIP_TRY(hipEventElapsedTime(&ms[2], e[1], e[2]));
+  HIP_TRY(hipEventElapsedTime(&ms[3], e[2], e[3]));
   return LT_OK;
 }
 
@@ -744,8 +767,8 @@ int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, i
   return LT_OK;
 }
 
-// 0 = fused chain kernel (window filter inside the per-chain workgroup), 1 = bulk metric kernel +
-// replay kernel (default).  Both give the same records up to the 1e-6 rounding of the lag metric.
+// 1 (default) = grid scan of the idle chains + per-chain kernel for the others; 0 = per-chain kernel for every
+// chain.  Same arithmetic on the same strips either way: identical records.
 int lt_batch_set_mode(lt_batch *b, int mode)
 {
   if (!b || (mode != 0 && mode != 1)) return fail(LT_ERROR_INVALID_INPUTS, "mode must be 0 or 1");
@@ -753,28 +776,13 @@ int lt_batch_set_mode(lt_batch *b, int mode)
   return LT_OK;
 }
 
-// Diagnostics only (tools/probe.py): ablate parts of the chain kernel to time the rest.
-// Not declared in the public header; results are meaningless while a flag is set.
-int lt_debug_set_ablation(lt_batch *b, int flags)
-{
-  if (!b) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
-  b->ablate = flags;
-  if ((flags & (8 | 256)) && !b->d_prof) { // 256: per-chain elapsed clocks of the product kernels
-    HIP_TRY(hipSetDevice(b->device));
-    const size_t bytes = (size_t)b->n_channels * 3 * 24 * sizeof(unsigned long long);
-    HIP_TRY(hipMalloc(&b->d_prof, bytes));
-    HIP_TRY(hipMemset(b->d_prof, 0, bytes));
-  }
-  return LT_OK;
-}
+int lt_batch_get_mode(lt_batch *b) { return b ? b->mode : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
 
-// Diagnostics only: shader-clock sums per phase, [n_channels*3][16], of the last run (flag 8).
-int lt_debug_get_profile(lt_batch *b, unsigned long long *out)
+int lt_batch_set_scan_segments(lt_batch *b, int first, int later)
 {
-  if (!b || !b->d_prof) return fail(LT_ERROR_INVALID_INPUTS, "profiling not enabled");
-  HIP_TRY(hipSetDevice(b->device));
-  if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
-  HIP_TRY(hipMemcpy(out, b->d_prof, (size_t)b->n_channels * 3 * 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (!b || first < 1 || later < 1) return fail(LT_ERROR_INVALID_INPUTS, "segment lengths must be >= 1 window");
+  b->seg_first = first;
+  b->seg_len = later;
   return LT_OK;
 }
 

@@ -1,0 +1,430 @@
+// Per-chain kernel: pss_impl::general_work (lib/pss_impl.cc:155-223) call by call for one (channel, N_id_2)
+// chain per workgroup, from wherever the chain stands: a chain the grid scan (lt_scan_kernels.h) has carried up
+// to the window that fired, a chain that is building its score or tracking, or -- with the scan switched
+// off (lt_batch_set_mode 0) -- any chain at all.  One record per call; the sss block's CP / SSS results are
+// added to the records afterwards by the per-record kernels in lt_kernels.hip.
+//
+// 12 waves, wave s = strip s of the window being searched (lt_scan.h): it fetches the strip's 1024 samples,
+// runs the forward transform, multiplies by the root's filter spectrum, transforms back and keeps the strip's
+// exponential average in 14 registers per lane -- the same instruction sequence as the scan's root waves, so both
+// give the same bits.  The 12 StripPartials meet in LDS and every wave resolves them redundantly
+// (resolve_window): one workgroup barrier per search.  A lobe too wide for the strips' 64-lag neighbourhoods
+// takes the exact path: the average goes to an LDS mirror and the walk of oracle/lte_oracle.c:300-316 runs on it.
+#pragma once
+#include "lt_scan_kernels.h"
+
+namespace lt {
+
+constexpr int kChainWaves = kStrips;
+constexpr int kChainThreads = 64 * kChainWaves;
+// farthest sample a call starting at pos can touch is pos + kCallReach - 1 (peak at lag 9725: the half-frame
+// [pos + 8765, pos + 18365)); lib/pss_impl.cc:185-195
+constexpr int kCallReach = (kNLags - 1 - kSlotLen) + kHalfFrame;
+
+struct ChainArgs {
+  const v2f *iq;       // [n_channels][ch_stride]
+  int64_t ch_stride;
+  const v2f *hist;     // [n_channels][hist_stride] or null
+  int64_t hist_stride;
+  int64_t t0, n, hist_len;
+  int flush;           // 1: the stream ends with this chunk (a chain runs while a whole window is left, and stops
+                       // at an emission that would reach past the end: quirk q1 normalised); 0: a call starts only
+                       // when everything it could touch is in the chunk
+  int n_channels;
+  ChainState *state;   // [n_channels*3], index channel*3 + n_id_2
+  const ScanJob *jobs;
+  lt_record *recs;     // [n_channels*3][rec_cap]
+  int rec_cap;
+  int *rec_count;      // [n_channels*3]: in = records the resolver wrote, out = records of the run
+  v2f *out_hf;         // nullable: [n_channels*3][out_cap][9600]
+  int out_cap;
+  const DeviceTables *tab;
+  float psr_threshold;
+  int track_after;
+  int track_every;
+};
+
+struct SearchResult {
+  int peak_pos;
+  float peak_value;
+  float psr;
+};
+
+// LDS of the chain kernel / the single-call find kernel
+struct ChainLds {
+  v2f E[kChainWaves * fft::kScratchW]; // exchange areas; the exact path's mirror of the average lives here too
+  fft::c32x2 TW1[16 * 64];
+  fft::c32x2 TW2[16 * 4];
+  v2f SPEC[fft::kN];
+  StripPartial parts[2][kStrips];      // two sets used in turn: no barrier between a resolve and the next search
+  float wave_out[kChainWaves];
+};
+static_assert(sizeof(v2f) * kChainWaves * fft::kScratchW >= sizeof(float) * (kConvLen + 8), "mirror must fit in the exchange areas");
+
+__device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *__restrict__ tab, int n_id_2)
+{
+  for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) L.TW1[i] = *reinterpret_cast<const fft::c32x2 *>(tab->fft_tw1[i]);
+  if (threadIdx.x < 64) L.TW2[threadIdx.x] = *reinterpret_cast<const fft::c32x2 *>(tab->fft_tw2[threadIdx.x]);
+  for (int i = threadIdx.x; i < fft::kN; i += blockDim.x) {
+    const cf32 h = tab->pss_spec[n_id_2][i];
+    L.SPEC[i] = v2f{h.re, h.im};
+  }
+}
+
+// lag metric + exponential average of the window at absolute position w0 (every wave its strip)
+__device__ __forceinline__ void chain_window_ema(ChainLds &L, const Capture &cap, int64_t w0, int w, int lane, float (&ema)[kStripRegs])
+{
+  fft::c32 x[16];
+  strip_load(cap, w0, w, lane, x);
+  fft::c32 *e = L.E + w * fft::kScratchW;
+  strip_fft<false>(lane, x, L.TW1, L.TW2, e);
+  strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
+}
+
+// srslte_pss_find_pss on the window at w0.  Contains workgroup barriers; `buf` alternates between calls.
+__device__ __forceinline__ SearchResult chain_search(ChainLds &L, const Capture &cap, int64_t w0, int w, int lane,
+                                                     float (&ema)[kStripRegs], int &buf)
+{
+  chain_window_ema(L, cap, w0, w, lane, ema);
+  StripPartial p;
+  strip_resolve(ema, w, lane, p);
+  StripPartial *parts = L.parts[buf];
+  buf ^= 1;
+  if (lane == 0) parts[w] = p;
+  __syncthreads();
+  const WindowResult r = resolve_window(parts);
+  SearchResult out;
+  out.peak_pos = __builtin_amdgcn_readfirstlane(r.peak_pos);
+  out.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.peak_value)));
+  out.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.psr)));
+  if (__builtin_amdgcn_readfirstlane((int)r.exact)) return out;
+  // ---- exact path (oracle/lte_oracle.c:295-316 on the whole vector): the peak is right as it is; the lobe
+  // walk and the side-lobe maximum run on a mirror of the average in LDS (the exchange areas are idle now)
+  float *M = reinterpret_cast<float *>(L.E);
+  strip_ema_store(M, w, lane, ema);
+  if (threadIdx.x < 8) M[kNLags + threadIdx.x] = 0.f;
+  __syncthreads();
+  const int peak = out.peak_pos;
+  int pl_ub = peak + 1;
+  for (int base = peak + 1;; base += 64) { // while (avg[pl_ub + 1] <= avg[pl_ub] && pl_ub < 9727) pl_ub++
+    const int u = base + lane;
+    bool stop = true;
+    if (u < kConvLen - 1) stop = !(M[u + 1] <= M[u]);
+    const unsigned long long m = __ballot(stop);
+    if (m) {
+      pl_ub = base + __builtin_ctzll(m);
+      break;
+    }
+  }
+  int pl_lb = 0;
+  if (peak > 2) {
+    for (int base = peak - 1;; base -= 64) { // while (avg[pl_lb - 1] <= avg[pl_lb] && pl_lb > 1) pl_lb--
+      const int u = base - lane;
+      bool stop = true;
+      if (u > 1) stop = !(M[u - 1] <= M[u]);
+      const unsigned long long m = __ballot(stop);
+      if (m) {
+        pl_lb = base - __builtin_ctzll(m);
+        break;
+      }
+    }
+  }
+  float o = -FLT_MAX; // maximum over the valid lags outside [pl_lb, pl_ub)
+  {
+    const int c0 = kStripPitch * w - kStripHalo;
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) {
+      const int off = lane + 64 * r, lag = c0 + off;
+      const bool own = off >= kStripHalo && off < kStripHalo + kStripPitch && lag < kNLags;
+      if (own && (lag < pl_lb || lag >= pl_ub) && ema[r] > o) o = ema[r];
+    }
+  }
+  o = wave_max_f(o);
+  if (lane == 0) L.wave_out[w] = o;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kChainWaves; ++k) o = fmaxf(o, L.wave_out[k]);
+  const float sl = (pl_lb == 0) ? M[0] : o;               // srslte_vec_max_fi of an empty range: its first element
+  const float sr = (kNLags - pl_ub <= 0) ? M[pl_ub] : o;
+  const float side = sl > sr ? sl : sr;
+  out.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(out.peak_value / side)));
+  __syncthreads(); // the mirror is read: the exchange areas may be used again
+  return out;
+}
+
+__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
+{
+  __shared__ ChainLds L;
+  __shared__ LdsTables ltab;
+  __shared__ float psr_data[kMovingAvgSz];
+  __shared__ float cfo_data[kMovingAvgSz];
+  __shared__ v2f RAW[kSymbolSz];
+  __shared__ v2f RAWb[kChainWaves][kSymbolSz]; // the PSS symbol of each wave's half-frame (batched tracked emits)
+  __shared__ float batch_cfo[kChainWaves];
+  __shared__ float sh_cfo, sh_mean_cfo;
+  constexpr int NT = kChainThreads, NW = kChainWaves;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chain = blockIdx.x, channel = chain / 3, n_id_2 = chain % 3;
+  ChainState *st = a.state + chain;
+  // a chain the scan has carried through all the windows it may search in this run has nothing left to do
+  const int scan_job = st->scan_job;
+  if (scan_job >= 0 && st->scan_live) return;
+
+  Capture cap;
+  cap.iq = a.iq + (int64_t)channel * a.ch_stride;
+  cap.hist = a.hist ? a.hist + (int64_t)channel * a.hist_stride : nullptr;
+  cap.t0 = a.t0;
+  cap.n = a.n;
+  cap.hist_len = a.hist ? a.hist_len : 0;
+  const int64_t t1 = a.t0 + a.n;
+  const DeviceTables *__restrict__ tab = a.tab;
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+
+  // ---- load state
+  float ema[kStripRegs];
+  float *avg = st->avg[st->ema_sel];
+  strip_ema_load(avg, w, lane, ema);
+  for (int i = tid; i < kMovingAvgSz; i += NT) {
+    psr_data[i] = st->psr_data[i];
+    cfo_data[i] = st->cfo_data[i];
+  }
+  chain_lds_init(L, tab, n_id_2);
+  load_lds_tables(ltab, tab, n_id_2);
+  int64_t pos = st->pos;
+  int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
+  int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
+  uint32_t psr_i = st->psr_i, cfo_i = st->cfo_i;
+  int n_emits = 0;
+  float psr = st->psr, psr_max = st->psr_max;
+  const float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg; // owned by lt_cp_scan_kernel; records carry the run's start values until then
+  int nrec = a.rec_count[chain]; // the misses the resolver has turned into records
+  const int call_base = st->n_calls - nrec;
+  int buf = 0;
+  __syncthreads();
+
+  // ---- a chain coming from the scan: its average is the one from before the scan segment in which it
+  // fired; bring it up to the window that fired (the resolver has written those windows' records)
+  if (scan_job >= 0) {
+    const int64_t pos0 = a.jobs[scan_job].pos0;
+    for (int k = st->scan_seg0; k < st->scan_done; ++k) chain_window_ema(L, cap, pos0 + (int64_t)k * kHalfFrame, w, lane, ema);
+  }
+
+  auto can_call = [&](int64_t p) { return a.flush ? p + kHalfFrame <= t1 : p + kCallReach <= t1; };
+  while (can_call(pos) && nrec < a.rec_cap) {
+    // ---- tracked chain between two searches (lib/pss_impl.cc:163-214 with timer > 0): the next `timer` calls
+    // neither search nor change the score; each emits the half-frame at its input position (peak_pos is 960
+    // since the emit of the last search).  Their CFO estimates are independent, so they run one per wave:
+    //   A  stage the PSS symbol and estimate the CFO                               (parallel)
+    //   B  ring mean with this call's and the earlier calls' estimates entered     (parallel, exact)
+    if (is_tracking && timer > 0 && !tracking_lost && peak_pos == kSlotLen && psr > a.psr_threshold) {
+      int nb = timer;
+      while (nb > 0 && !can_call(pos + (int64_t)(nb - 1) * kHalfFrame)) --nb;
+      if (a.rec_cap - nrec < nb) nb = a.rec_cap - nrec;
+      for (int done = 0; done < nb; done += NW) {
+        const int nr = (nb - done < NW) ? nb - done : NW;
+        const bool act = w < nr;
+        const int idx = done + w; // call within the batch
+        const int64_t hf0 = pos + (int64_t)idx * kHalfFrame;
+        float c = 0.f, mc = 0.f;
+        if (act) {
+          for (int i = lane; i < kSymbolSz; i += 64) RAWb[w][i] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + i);
+          c = cfo_estimate_wave(ltab.taps, RAWb[w]);
+          if (lane == 0) batch_cfo[w] = c;
+        }
+        __syncthreads();
+        const uint32_t slot0 = cfo_i % kMovingAvgSz;
+        float ring_new = 0.f;
+        if (tid < nr) ring_new = batch_cfo[tid];
+        v2f *out = nullptr;
+        if (act) {
+          mc = moving_avg_wave(cfo_data, cfo_i + (uint32_t)w + 1u, slot0, batch_cfo, (uint32_t)w + 1u);
+          if (a.out_hf && n_emits + idx < a.out_cap) out = a.out_hf + ((int64_t)chain * a.out_cap + n_emits + idx) * kHalfFrame;
+        }
+        __syncthreads(); // every wave has read the ring
+        if (tid < nr) cfo_data[(slot0 + tid) % kMovingAvgSz] = ring_new;
+        if (act) {
+          // rotation, CP decision and SSS feed nothing here: lt_cp_kernel / lt_cp_scan_kernel / lt_sss_kernel
+          if (lane == 0) {
+            lt_record r;
+            r.in_pos = hf0; r.out_pos = hf0; r.channel = channel; r.n_id_2 = n_id_2;
+            r.call_idx = call_base + nrec + idx; r.flags = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
+            r.peak_pos = kSlotLen; r.score = score;
+            r.psr = psr; r.peak_value = 0.f; r.cfo = c; r.mean_cfo = mc;
+            r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+            r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+            r.psr_max = psr_max; r.timer = timer - 1 - idx;
+            recs[nrec + idx] = r;
+          }
+          if (out) {
+            const float freq = -mc / (float)kSymbolSz;
+            const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+            for (int i = lane; i < kHalfFrame; i += 64) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
+          }
+        }
+        cfo_i += (uint32_t)nr;
+      }
+      if (nb > 0) {
+        timer -= nb;
+        nrec += nb;
+        n_emits += nb;
+        pos += (int64_t)nb * kHalfFrame;
+        continue;
+      }
+      break; // the next call does not fit into this chunk
+    }
+
+    uint32_t flags = 0;
+    float peak_value = 0.f;
+    // ---- lib/pss_impl.cc:163-172
+    if (!is_tracking || timer == 0) {
+      timer = a.track_every;
+      const SearchResult r = chain_search(L, cap, pos, w, lane, ema, buf);
+      peak_pos = r.peak_pos;
+      psr = r.psr;
+      peak_value = r.peak_value;
+      if (tid == 0) psr_data[psr_i % kMovingAvgSz] = psr;
+      psr_i++;
+      flags |= LT_F_SEARCHED;
+    } else {
+      timer--;
+    }
+    const int used_peak_pos = peak_pos;
+
+    // ---- score, lib/pss_impl.cc:174-182 (incr_score :111-127, reset_score :129-152)
+    const bool over = psr > a.psr_threshold;
+    if (over) {
+      if (!(is_tracking && score == a.track_after)) {
+        score++;
+        if (!is_tracking && score == a.track_after) {
+          is_tracking = 1;
+#pragma unroll
+          for (int t = 0; t < kStripRegs; ++t) ema[t] = 0.f; // srslte_pss_reset
+        }
+      }
+      flags |= LT_F_OVER;
+    } else if (score != 0) {
+      score = 0;
+      timer = 0;
+      is_tracking = 0;
+#pragma unroll
+      for (int t = 0; t < kStripRegs; ++t) ema[t] = 0.f;
+      psr_i = 0;
+      cfo_i = 0;
+      tracking_lost = 1;
+    }
+    if (psr > psr_max) psr_max = psr;
+
+    int64_t out_pos = -1, next_pos;
+    float cfo = 0.f, mean_cfo = 0.f;
+
+    if (over || tracking_lost) { // ---- lib/pss_impl.cc:184-214
+      const int frame_start = peak_pos - kSlotLen;
+      peak_pos = kSlotLen;
+      const int64_t hf0 = pos + frame_start;
+      if (hf0 + kHalfFrame > t1) break; // (flush only) quirk q1 normalised: never read past the capture
+      next_pos = hf0 + kHalfFrame;
+      out_pos = hf0;
+      flags |= LT_F_EMITTED;
+      v2f *out = (a.out_hf && n_emits < a.out_cap) ? a.out_hf + ((int64_t)chain * a.out_cap + n_emits) * kHalfFrame : nullptr;
+      if (is_tracking) {
+        // CFO estimate on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring update and mean_cfo() -- the
+        // chain's only emit-side state.  Rotation of the half-frame, CP decision and SSS feed nothing in this
+        // kernel: lt_cp_kernel / lt_cp_scan_kernel / lt_sss_kernel run them afterwards from the record.
+        if (tid < kSymbolSz) RAW[tid] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + tid);
+        __syncthreads();
+        if (tid < 64) {
+          const float c = cfo_estimate_wave(ltab.taps, RAW);
+          const uint32_t slot = cfo_i % kMovingAvgSz;
+          const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c);
+          if (tid == 0) {
+            cfo_data[slot] = c;
+            sh_cfo = c;
+            sh_mean_cfo = mc;
+          }
+        }
+        __syncthreads();
+        cfo_i++;
+        cfo = sh_cfo;
+        mean_cfo = sh_mean_cfo;
+        if (out) {
+          const float freq = -mean_cfo / (float)kSymbolSz; // srslte_cfo_correct, lib/pss_impl.cc:204
+          const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+          for (int i = tid; i < kHalfFrame; i += NT) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
+        }
+        flags |= LT_F_SSS_RAN;
+      } else {
+        // tracking lost: tag the half-frame (lib/pss_impl.cc:210-214); sss resets on the tag (lib/sss_impl.cc:91-100)
+        flags |= LT_F_TAG_LOST;
+        tracking_lost = 0;
+        if (out)
+          for (int i = tid; i < kHalfFrame; i += NT) out[i] = ld_abs(cap, hf0 + i);
+      }
+      n_emits++;
+    } else {
+      next_pos = pos + kHalfFrame; // lib/pss_impl.cc:217
+    }
+
+    if (is_tracking) flags |= LT_F_TRACKING;
+    if (tid == 0) {
+      lt_record r;
+      r.in_pos = pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
+      r.call_idx = call_base + nrec; r.flags = flags; r.peak_pos = used_peak_pos; r.score = score;
+      r.psr = psr; r.peak_value = peak_value; r.cfo = cfo; r.mean_cfo = mean_cfo;
+      r.m_norm_avg = m_norm_avg; r.m_ext_avg = m_ext_avg; r.m0_value = 0.f;
+      r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+      r.psr_max = psr_max; r.timer = timer;
+      recs[nrec] = r;
+    }
+    nrec++;
+    pos = next_pos;
+  }
+
+  // ---- store state
+  __syncthreads();
+  strip_ema_store(avg, w, lane, ema);
+  for (int i = tid; i < kMovingAvgSz; i += NT) {
+    st->psr_data[i] = psr_data[i];
+    st->cfo_data[i] = cfo_data[i];
+  }
+  if (tid == 0) {
+    st->pos = pos;
+    st->is_tracking = is_tracking; st->score = score; st->timer = timer;
+    st->tracking_lost = tracking_lost; st->peak_pos = peak_pos;
+    st->psr_i = psr_i; st->cfo_i = cfo_i;
+    st->n_calls = call_base + nrec; st->n_emits += n_emits;
+    st->psr = psr; st->psr_max = psr_max;
+    a.rec_count[chain] = nrec;
+  }
+}
+
+// srslte_pss_find_pss for one handle (lt_pss_find_pss): window = 9600 device samples, avg = 9728-float state.
+struct FindResult {
+  int peak_pos;
+  float psr;
+  float peak_value;
+};
+__global__ __launch_bounds__(kChainThreads) void lt_find_kernel(const v2f *__restrict__ win, float *avg,
+                                                                const DeviceTables *__restrict__ tab, int n_id_2, FindResult *res)
+{
+  __shared__ ChainLds L;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Capture cap;
+  cap.iq = win; cap.hist = nullptr; cap.t0 = 0; cap.n = kHalfFrame; cap.hist_len = 0;
+  float ema[kStripRegs];
+  strip_ema_load(avg, w, lane, ema);
+  chain_lds_init(L, tab, n_id_2);
+  __syncthreads();
+  int buf = 0;
+  const SearchResult r = chain_search(L, cap, 0, w, lane, ema, buf);
+  strip_ema_store(avg, w, lane, ema);
+  if (tid == 0) {
+    res->peak_pos = r.peak_pos;
+    res->psr = r.psr;
+    res->peak_value = r.peak_value;
+  }
+}
+
+} // namespace lt

@@ -1,16 +1,10 @@
-// Device-side building blocks of the gfx950 LTE cell-search path.
+// Device-side building blocks of the gfx950 LTE cell-search path shared by all kernels: the chain state, wave
+// reductions, and the emit-side stages (CFO estimate and correction, CP detection, SSS) of
+// pss_impl::general_work / sss_impl::work.  The search itself (srslte_pss_find_pss) lives in lt_scan.h.
 //
-// Work decomposition (one workgroup = one pss->sss chain = one (channel, N_id_2)):
-//   fused kernel: 512 threads (8 wave64), thread `tid` owns the 19 consecutive lags [19*tid, 19*tid+19) of
-//   the 9728-lag linear convolution of a 9600-sample half-frame window with the 128-tap PSS filter
-//   (512 * 19 = 9728 exactly); the window sits zero-padded in LDS.
-//   replay kernel: 256 threads, thread `tid` owns lags tid, tid + 256, ... (38 of them), the order the
-//   precomputed lag metric arrives in.
-//   Either way the EMA of the lag metric lives in registers and never touches HBM between windows.
-//
-// Arithmetic rules: the library is built with -ffp-contract=off; the only fused operations are
-// the explicit FMAs of the matched filter and of the CFO rotation.  Everything downstream of the
-// lag metric is evaluated in the oracle's operation order so that it is bit-exact against it.
+// Arithmetic rules: the library is built with -ffp-contract=off; the only fused operations are the explicit
+// FMAs of the transforms and of the CFO rotation.  Everything downstream of the lag metric is evaluated in the
+// oracle's operation order so that it is bit-exact against it.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -31,22 +25,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // back as an instruction offset; for an array at LDS offset 0 the rebased flat address leaves the LDS
 // aperture and the access faults.)
 
-constexpr int kThreads = 512;
-constexpr int kThreadsReplay = 256; // workgroup of the replay kernel (bulk + replay mode)
-constexpr int kWaves = kThreads / 64;
-constexpr int kT = 19;                              // lags per thread
-constexpr int kWPad = 128;                          // zero samples in front of the window in LDS
-constexpr int kWLen = 10240;                        // 81920 B: window + zero pads; doubles as FFT scratch (9 x 8448 B)
-constexpr int kAvgLen = kConvLen + 4;               // EMA mirror in LDS, [9728] is the always-zero lag
 constexpr int kSssBase = 480;                       // first half-frame sample the sss stage touches
 constexpr int kSssLen = kSlotLen - kSssBase;        // 480 samples [480, 960)
-constexpr int kBlkValid = fft::kN - (kSymbolSz - 1);  // 897 valid lags per 1024-point overlap-save block
-constexpr int kBlocks = (kConvLen + kBlkValid - 1) / kBlkValid; // 11
-static_assert(kThreads * kT == kConvLen, "lag tiling must cover the convolution exactly");
-static_assert(kWPad + (kBlocks - 1) * kBlkValid - (kSymbolSz - 1) + fft::kN <= kWLen, "window buffer too short");
-constexpr int kScratchInW = kWLen / fft::kScratch;    // 9 transforms' scratch fit in the window buffer
-static_assert(kBlocks <= 2 * kWaves, "one half-wave per overlap-save block");
-static_assert((kBlocks - kScratchInW) * fft::kScratch * 2 <= kAvgLen, "remaining scratch must fit in the metric buffer");
 
 // Persistent state of one chain (pss_impl + sss_impl members, lib/pss_impl.h:41-81,
 // lib/sss_impl.h:42-44), kept in HBM between launches.
@@ -74,80 +54,6 @@ struct ChainState {
   float cfo_data[kMovingAvgSz];
   float avg[2][kConvLen]; // srslte_pss_t::conv_output_avg (lags >= 9726 stay 0), natural lag order
 };
-
-// LDS scratch for block reductions and the sss stage.
-struct Scratch {
-  float tmax[kThreads]; // per-thread maximum of the EMA over its valid lags
-  int tidx[kThreads];   // lag of that maximum
-  v2f Y[62];           // occupied bins of the SSS symbol's FFT
-  float cfo, mean_cfo; // wave 0 -> everyone
-};
-
-struct SearchResult {
-  int peak_pos;
-  float peak_value;
-  float psr;
-};
-
-__device__ __forceinline__ v2f ld_iq(const v2f *__restrict__ x, int64_t n, int64_t i)
-{
-  // "zero history at stream start" (set_history, lib/pss_impl.cc:81); nothing past the capture
-  v2f z = {0.f, 0.f};
-  return (i < 0 || i >= n) ? z : x[i];
-}
-
-// acc += h * u (complex), two packed FMAs: (hx,hx)*(ux,uy) and (-hy,hy)*(uy,ux)
-__device__ __forceinline__ v2f cmac(v2f acc, v2f h, v2f u)
-{
-  v2f hxx = {h.x, h.x};
-  v2f hyy = {-h.y, h.y};
-  v2f uyx = {u.y, u.x};
-  acc = __builtin_elementwise_fma(hxx, u, acc);
-  acc = __builtin_elementwise_fma(hyy, uyx, acc);
-  return acc;
-}
-
-// 19 lags of the 128-tap matched filter, using the even symmetry h[m] = h[128-m] of the PSS
-// filter (d[n] = d[61-n] in 36.211 6.11.1.1):
-//   conv[n] = h[0] w[n] + h[64] w[n-64] + sum_{m=1..63} h[m] (w[n-m] + w[n-128+m])
-// Wp points at w[n0] inside the zero-padded LDS window; taps = h[0..64] (wave-uniform).
-__device__ __forceinline__ void conv19(const v2f *Wp, const v2f *__restrict__ taps, v2f acc[kT])
-{
-  {
-    const v2f h0 = taps[0], h64 = taps[64];
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      v2f z = {0.f, 0.f};
-      z = cmac(z, h0, Wp[t]);
-      acc[t] = cmac(z, h64, Wp[t - 64]);
-    }
-  }
-  for (int c = 0; c < 7; ++c) { // taps m0 .. m0+8
-    const int m0 = 1 + 9 * c;
-    const v2f *A = Wp - m0 - 8;   // A[i] = w[n0 - m0 - 8 + i];  w[n0+t-(m0+j)]     = A[t-j+8]
-    const v2f *B = Wp - 128 + m0; // B[i] = w[n0 - 128 + m0 + i]; w[n0+t-128+(m0+j)] = B[t+j]
-    v2f a[kT + 8], b[kT + 8];
-#pragma unroll
-    for (int i = 0; i < kT + 8; ++i) {
-      a[i] = A[i];
-      b[i] = B[i];
-    }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const v2f h = taps[m0 + j];
-#pragma unroll
-      for (int t = 0; t < kT; ++t) acc[t] = cmac(acc[t], h, a[t - j + 8] + b[t + j]);
-    }
-  }
-}
-
-__device__ __forceinline__ void argmax_combine(float &v, int &i, float ov, int oi)
-{
-  if (ov > v || (ov == v && oi < i)) {
-    v = ov;
-    i = oi;
-  }
-}
 
 // ---- wavefront reductions on the VALU cross-lane path (DPP row rotates + 4 readlanes) instead of
 // ds_bpermute: every lane of a 16-lane row ends up with the row's result, the four rows are then
@@ -198,9 +104,6 @@ __device__ __forceinline__ float wave_max_f(float f)
   return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
-// srslte_pss_find_pss on the window held in W (LDS, zero padded): lag metric, EMA(0.2),
-// arg-max, main-lobe walk, peak-to-side-lobe ratio (call site lib/pss_impl.cc:165).
-// `ema` is this thread's slice of conv_output_avg.  Contains __syncthreads().
 // value of lane (l ^ kMask): DPP quad permutes for 1 and 2, ds_swizzle (bit mode) up to 16,
 // ds_bpermute for 32
 template <int kMask> __device__ __forceinline__ int lane_xor_i(int v)
@@ -217,469 +120,6 @@ template <int kMask> __device__ __forceinline__ float lane_xor(float v)
 template <int kMask> __device__ __forceinline__ double lane_xor_d(double v)
 {
   return __hiloint2double(lane_xor_i<kMask>(__double2hiint(v)), lane_xor_i<kMask>(__double2loint(v)));
-}
-
-// Overlap-save matched filter: |conv[lag]|^2 for all 9728 lags of the window in W, written to
-// `metric` (LDS).  Block b (1024 samples starting 127 before lag 897 b) is transformed by one
-// half-wave (csrc/lt_fft.h): FFT-1024, multiply by the filter spectrum, inverse FFT, keep the
-// 897 alias-free outputs; 11 blocks = 11 of the 16 half-waves, one
-// round.  Once every half-wave holds its 1024 inputs in registers, the window buffer (and, for the
-// last two blocks, the still unused metric buffer) serves as the FFT exchange scratch.  Three
-// __syncthreads() inside; W is garbage afterwards, `metric` complete.
-__device__ __forceinline__ void conv_metric_fft(v2f *W, float *metric, const v2f *tw, const v2f *spec,
-                                                unsigned long long *prof = nullptr)
-{
-  unsigned long long tq_ = prof ? __builtin_amdgcn_s_memtime() : 0;
-#define LT_FSTAMP(i)                                             \
-  if (prof) {                                                    \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    prof[i] += t_ - tq_;                                         \
-    tq_ = t_;                                                    \
-  }
-  const int l = threadIdx.x & 31, b = threadIdx.x >> 5; // lane within the half-wave, block index
-  const bool active = b < kBlocks;
-  fft::c32 v[32];
-  if (active) {
-    const v2f *p = W + kWPad + b * kBlkValid - (kSymbolSz - 1) + l;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r] = p[32 * r];
-  }
-  __syncthreads(); // every half-wave holds its inputs: W may now be overwritten
-  LT_FSTAMP(14)
-  if (active) {
-    fft::c32 *e = (b < kScratchInW) ? W + b * fft::kScratch
-                                    : reinterpret_cast<fft::c32 *>(metric) + (b - kScratchInW) * fft::kScratch;
-    fft::fft1024_stage1<false>(l, v, tw, e);
-    fft::fft1024_stage2<false>(l, v, e);
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r] = fft::cmul<false>(v[r], spec[r * 32 + l]);
-    fft::fft1024_stage1<true>(l, v, tw, e);
-    fft::fft1024_stage2<true>(l, v, e);
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = __fadd_rn(__fmul_rn(v[r].x, v[r].x), __fmul_rn(v[r].y, v[r].y));
-  }
-  LT_FSTAMP(15)
-  __syncthreads(); // no scratch in use any more: the metric buffer may be written
-  if (active) {
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      const int i = l + 32 * r;
-      const int lag = b * kBlkValid + i - (kSymbolSz - 1);
-      if (i >= kSymbolSz - 1 && lag < kConvLen) metric[lag] = v[r].x;
-    }
-  }
-  __syncthreads(); // metric[] complete
-  LT_FSTAMP(16)
-#undef LT_FSTAMP
-}
-
-#define LT_STAMP(i)                                              \
-  if (prof) {                                                    \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    prof[i] += t_ - t_prev;                                      \
-    t_prev = t_;                                                 \
-  }
-// Part 1 (search_front): matched filter, EMA, LDS mirror, ends with the block-wide barrier; after it
-// the window buffer W is no longer read.  Part 2 (search_tail): arg-max, walk, side lobes, PSR.
-struct FilterLds {
-  const v2f *tw;   // FFT twiddles W1024^(reg*lane), [32][32], in LDS
-  const v2f *spec; // filter spectrum / 1024, natural order, in LDS
-};
-
-__device__ __forceinline__ void search_ema(const float met[kT], float *AVG, float ema[kT], Scratch &sc, int ablate,
-                                           unsigned long long *prof);
-
-__device__ __forceinline__ void search_front(v2f *W, float *AVG, float ema[kT],
-                                             const v2f *__restrict__ taps, const FilterLds &fl, Scratch &sc,
-                                             int ablate, unsigned long long *prof = nullptr)
-{
-  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
-  const int tid = threadIdx.x;
-  const int n0 = tid * kT;
-
-  // lag metric |conv|^2 of this thread's 19 lags
-  float met[kT];
-  if (ablate & 2) { // diagnostics: no matched filter
-#pragma unroll
-    for (int t = 0; t < kT; ++t) met[t] = W[kWPad + n0 + t].x;
-  } else if (ablate & 16) { // direct-form reference path (folded 128-tap FIR), kept for A/B checks
-    v2f acc[kT];
-    conv19(W + kWPad + n0, taps, acc);
-#pragma unroll
-    for (int t = 0; t < kT; ++t) met[t] = __fadd_rn(__fmul_rn(acc[t].x, acc[t].x), __fmul_rn(acc[t].y, acc[t].y));
-  } else {
-    conv_metric_fft(W, AVG, fl.tw, fl.spec, prof); // AVG doubles as the staging area of the metric
-#pragma unroll
-    for (int t = 0; t < kT; ++t) met[t] = AVG[n0 + t];
-  }
-  LT_STAMP(0) // matched filter
-  search_ema(met, AVG, ema, sc, ablate, prof);
-}
-
-// EMA of the lag metric (three roundings like srsLTE's three vector passes), LDS mirror, per-thread
-// maxima; ends with the block-wide barrier.  met[t] = |conv|^2 of lag 19 tid + t.
-__device__ __forceinline__ void search_ema(const float met[kT], float *AVG, float ema[kT], Scratch &sc, int ablate,
-                                           unsigned long long *prof)
-{
-  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
-  const int tid = threadIdx.x;
-  const int n0 = tid * kT;
-  if (ablate & 4) { // diagnostics: no reductions
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      ema[t] = met[t];
-      s += ema[t];
-    }
-    AVG[n0] = s;
-    __syncthreads();
-    return;
-  }
-  // EMA with three roundings like srsLTE's three vector passes, local first-maximum
-  float bv = -FLT_MAX;
-  int bi = INT_MAX;
-#pragma unroll
-  for (int t = 0; t < kT; ++t) {
-    const int lag = n0 + t;
-    const float a = met[t];
-    if (lag < kNLags) {
-      ema[t] = __fadd_rn(__fmul_rn(a, 0.2f), __fmul_rn(ema[t], 1.0f - 0.2f));
-      if (ema[t] > bv) {
-        bv = ema[t];
-        bi = lag;
-      }
-    }
-    AVG[lag] = ema[t];
-  }
-  sc.tmax[tid] = bv; // per-thread maximum over its 19 lags (valid lags only) and where it sits
-  sc.tidx[tid] = bi;
-  LT_STAMP(1) // EMA + LDS mirror
-  __syncthreads(); // the only block-wide synchronisation of the search: AVG, tmax, tidx are visible
-  LT_STAMP(2) // barrier wait
-}
-
-__device__ __forceinline__ SearchResult search_tail(const float *AVG, const Scratch &sc, int ablate,
-                                                   unsigned long long *prof = nullptr)
-{
-  const int lane = threadIdx.x & 63;
-  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
-  if (ablate & 4) {
-    SearchResult r0;
-    r0.peak_pos = __builtin_amdgcn_readfirstlane((int)AVG[4] & 1023);
-    r0.peak_value = 1.f;
-    r0.psr = 1.f;
-    return r0;
-  }
-  // Every wave redundantly derives the same (wave-uniform) results from LDS, so no further
-  // barrier is needed to broadcast them.
-  // ---- arg-max: first maximum = largest value, smallest lag among equals
-  float bv = -FLT_MAX;
-  int bi = INT_MAX;
-#pragma unroll
-  for (int k = 0; k < kThreads / 64; ++k) argmax_combine(bv, bi, sc.tmax[lane + 64 * k], sc.tidx[lane + 64 * k]);
-  {
-    const float wv = wave_max_f(bv);
-    bi = wave_min_i(bv == wv ? bi : INT_MAX);
-    bv = wv;
-  }
-  const int peak = (bi == INT_MAX) ? 0 : bi; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
-  const float peak_value = AVG[peak];
-  LT_STAMP(3) // arg-max
-
-  // ---- main-lobe walk, 64 lags per step in each direction:
-  //   pl_ub = first u >= peak+1 with !(avg[u+1] <= avg[u]) or u >= 9727
-  //   pl_lb = last  l <= peak-1 with !(avg[l-1] <= avg[l]) or l <= 1      (0 when peak <= 2)
-  int pl_ub = 0, pl_lb = 0;
-  for (int base = peak + 1;; base += 64) {
-    const int u = base + lane;
-    bool stop = false;
-    if (u <= kConvLen - 1) stop = !(AVG[u + 1] <= AVG[u]) || u >= kConvLen - 1;
-    const unsigned long long m = __ballot(stop);
-    if (m) {
-      pl_ub = base + __builtin_ctzll(m);
-      break;
-    }
-  }
-  if (peak > 2) {
-    for (int base = peak - 1;; base -= 64) {
-      const int u = base - lane;
-      bool stop = false;
-      if (u >= 1) stop = !(AVG[u - 1] <= AVG[u]) || u <= 1;
-      const unsigned long long m = __ballot(stop);
-      if (m) {
-        pl_lb = base - __builtin_ctzll(m);
-        break;
-      }
-    }
-  }
-
-  LT_STAMP(4) // walk
-  // ---- side lobes: max over [0, pl_lb) and over [pl_ub, 9726).  Threads whose 19 lags lie
-  // entirely on one side contribute their stored maximum; the two threads cut by the lobe
-  // contribute their outside elements one by one.
-  const int tL = pl_lb / kT, tU = pl_ub / kT;
-  float sl = -FLT_MAX, sr = -FLT_MAX;
-#pragma unroll
-  for (int k = 0; k < kThreads / 64; ++k) {
-    const int t = lane + 64 * k;
-    const float v = sc.tmax[t];
-    if (t < tL && v > sl) sl = v;
-    if (t > tU && v > sr) sr = v;
-  }
-  if (lane < kT) {
-    const int u = tL * kT + lane;
-    if (u < pl_lb) {
-      const float v = AVG[u];
-      if (v > sl) sl = v;
-    }
-  } else if (lane < 2 * kT) {
-    const int u = pl_ub + (lane - kT);
-    if (u < (tU + 1) * kT && u < kNLags) {
-      const float v = AVG[u];
-      if (v > sr) sr = v;
-    }
-  }
-  sl = wave_max_f(sl);
-  sr = wave_max_f(sr);
-  // an empty range makes srslte_vec_max_fi return index 0 of that range
-  if (pl_lb == 0) sl = AVG[0];
-  if (kNLags - pl_ub <= 0) sr = AVG[pl_ub];
-  const float side = sl > sr ? sl : sr;
-
-  LT_STAMP(5) // side lobes
-  // wave-uniform values: pin them to scalar registers
-  SearchResult r;
-  r.peak_pos = __builtin_amdgcn_readfirstlane(peak);
-  r.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value)));
-  r.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value / side)));
-  return r;
-}
-#undef LT_STAMP
-
-__device__ __forceinline__ SearchResult search_window(v2f *W, float *AVG, float ema[kT],
-                                                     const v2f *__restrict__ taps, const FilterLds &fl,
-                                                     Scratch &sc, int ablate)
-{
-  search_front(W, AVG, ema, taps, fl, sc, ablate);
-  return search_tail(AVG, sc, ablate);
-}
-
-// ---- bulk + replay mode: the interior lags 127..9599 of a window come from the position-independent
-// metric P[pos + lag] computed once per channel by lt_metric_kernel; only the 253 edge lags, whose
-// convolution sums are cut by the window's zero padding, are recomputed here.
-//   head lag j      (j = 0..126): sum_{m=0}^{j}     h[m] x[pos + j - m]
-//   tail lag 9600+j (j = 0..125): sum_{m=j+1}^{127} h[m] x[pos + 9600 + j - m]
-// With Z = [ x[pos+9472 .. pos+9600) | x[pos .. pos+128) ] (256 samples staged in LDS by the caller)
-// both sums read Z[128 + j - m]: taps m <= j fall into the head half, the others into the tail half,
-// so "unit" j walks all 128 taps once and yields head lag j and tail lag 9600+j.  Four lanes share a
-// unit, taps m = q, q+4, q+8, ... each (fixed trip count: the LDS loads batch; neighbouring lanes
-// read neighbouring or identical words: no bank conflicts); a lane's accumulator is moved aside
-// where its taps cross from head to tail; the four partial sums meet in an xor butterfly.
-// Items first, first+stride, ... < 512 are processed (item = 4 * unit + q).
-__device__ __forceinline__ void edge_lags(const v2f *Z, const v2f *taps, float *head, float *tail, int first, int stride)
-{
-  for (int item = first; item < 512; item += stride) { // trip count must be wave-uniform (DPP below)
-    const int j_raw = item >> 2, q = item & 3;
-    const int j = j_raw < 127 ? j_raw : 126; // items 508..511 are padding
-    const int b = (j - q + 4) >> 2;          // leading taps of this lane (m = q + 4 i <= j) that are head taps
-    const v2f *zp = Z + 128 + j - q;         // sample of tap q + 4 i = zp[-4 i]
-    const v2f *hp = taps + q;
-    float re = 0.f, im = 0.f, hre = 0.f, him = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const v2f h = hp[4 * i], z = zp[-4 * i];
-      re = fmaf(h.x, z.x, re);
-      re = fmaf(-h.y, z.y, re);
-      im = fmaf(h.x, z.y, im);
-      im = fmaf(h.y, z.x, im);
-      if (i + 1 == b) { // last head tap of the range: what follows belongs to the tail lag
-        hre = re; him = im;
-        re = 0.f; im = 0.f;
-      }
-    }
-    hre += lane_xor<1>(hre); him += lane_xor<1>(him); re += lane_xor<1>(re); im += lane_xor<1>(im);
-    hre += lane_xor<2>(hre); him += lane_xor<2>(him); re += lane_xor<2>(re); im += lane_xor<2>(im);
-    if (q == 0 && j_raw < 127) {
-      head[j] = __fadd_rn(__fmul_rn(hre, hre), __fmul_rn(him, him));                 // lag j
-      if (j < 126) tail[j] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));        // lag 9600 + j
-    }
-  }
-}
-
-// ---- bulk + replay mode search: srslte_pss_find_pss downstream of the lag metric with the lags
-// dealt out round-robin (thread t owns lags t, t + NT, t + 2 NT, ...), which is the order the
-// metric slice arrives in from HBM, so nothing is staged through LDS on the way in.
-template <int NT> struct BulkShared {
-  float tmax[2][NT]; // per-thread maximum of the EMA over its valid lags (two sets used in turn)
-  int tidx[2][NT];   // lag of that maximum
-  float edge[256];   // edge lags computed in the kernel: [0,127) head lags, [127,253) lags 9600..9725
-  float sl[NT / 64]; // wide main lobes only: per-wave side-lobe maxima
-};
-
-// EMA (three roundings like srsLTE's three vector passes), LDS mirror, per-thread first maximum.
-// No barrier inside: the caller issues its prefetch, then calls bulk_search_tail.
-template <int NT, int NL>
-__device__ __forceinline__ void bulk_search_ema(const float (&met)[NL], float (&ema)[NL], float *AVG, float *tmax, int *tidx)
-{
-  const int tid = threadIdx.x;
-  float bv = -FLT_MAX;
-  int bi = INT_MAX;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int lag = tid + i * NT;
-    if (lag < kNLags) {
-      ema[i] = __fadd_rn(__fmul_rn(met[i], 0.2f), __fmul_rn(ema[i], 1.0f - 0.2f));
-      if (ema[i] > bv) { // lags ascend with i: the first maximum of this thread
-        bv = ema[i];
-        bi = lag;
-      }
-    }
-    AVG[lag] = ema[i];
-  }
-  tmax[tid] = bv;
-  tidx[tid] = bi;
-}
-
-// arg-max, main-lobe walk, side lobes, PSR.  One block-wide barrier, after which every wave derives
-// the same (wave-uniform) results from LDS on its own.  `ema` = this thread's EMA values.
-//
-// Side lobes: srsLTE takes max(max over [0, pl_lb), max over [pl_ub, 9726)), an empty range standing
-// for the first element of where it would start (srslte_vec_max_fi returns index 0).  The maximum over
-// the lags outside the main lobe is assembled from the per-thread maxima: a thread whose maximum lies
-// outside the lobe contributes it as it is; the lags inside the lobe belong to pl_ub - pl_lb threads,
-// whose remaining lags are looked up in the LDS mirror one by one (a handful for the usual narrow
-// lobe; lobes wider than 64 lags take a second barrier and a masked pass over the registers instead).
-// (Superseded in part: only threads whose own maximum lies inside the lobe are looked up.)
-template <int NT, int NL>
-__device__ __forceinline__ SearchResult bulk_search_tail(const float (&ema)[NL], const float *AVG, const float *tmax,
-                                                         const int *tidx, float *wave_sl,
-                                                         unsigned long long *prof = nullptr)
-{
-  unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
-#define LT_BSTAMP(i)                                             \
-  if (prof) {                                                    \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    prof[i] += t_ - t_prev;                                      \
-    t_prev = t_;                                                 \
-  }
-  const int tid = threadIdx.x, lane = tid & 63;
-  __syncthreads(); // AVG mirror and per-thread maxima visible
-  LT_BSTAMP(2) // barrier
-  float tv[NT / 64];
-  int ti[NT / 64];
-  float bv = -FLT_MAX;
-  int bi = INT_MAX;
-#pragma unroll
-  for (int k = 0; k < NT / 64; ++k) {
-    tv[k] = tmax[lane + 64 * k];
-    ti[k] = tidx[lane + 64 * k];
-    argmax_combine(bv, bi, tv[k], ti[k]);
-  }
-  {
-    const float wv = wave_max_f(bv);
-    const unsigned long long holders = __ballot(bv == wv);
-    if (__builtin_popcountll(holders) == 1) bi = __builtin_amdgcn_readlane(bi, __builtin_ctzll(holders)); // the usual case
-    else bi = wave_min_i(bv == wv ? bi : INT_MAX);
-  }
-  const int peak = (bi == INT_MAX) ? 0 : bi; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
-  const float peak_value = AVG[peak];
-  LT_BSTAMP(3) // arg-max
-
-  // main-lobe walk, 64 lags per step, both directions in the same turn (their LDS round trips overlap):
-  //   pl_ub = first u >= peak+1 with !(avg[u+1] <= avg[u]) or u >= 9727
-  //   pl_lb = last  l <= peak-1 with !(avg[l-1] <= avg[l]) or l <= 1      (0 when peak <= 2)
-  const float q_left = AVG[0];
-  int pl_ub = 0, pl_lb = 0, up_base = peak + 1, dn_base = peak - 1;
-  bool up_done = false, dn_done = !(peak > 2);
-  for (;;) {
-    unsigned long long mu = 0, md = 0;
-    if (!up_done) {
-      const int u = up_base + lane;
-      bool stop = false;
-      if (u <= kConvLen - 1) stop = !(AVG[u + 1] <= AVG[u]) || u >= kConvLen - 1;
-      mu = __ballot(stop);
-    }
-    if (!dn_done) {
-      const int u = dn_base - lane;
-      bool stop = false;
-      if (u >= 1) stop = !(AVG[u - 1] <= AVG[u]) || u <= 1;
-      md = __ballot(stop);
-    }
-    if (!up_done) {
-      if (mu) {
-        pl_ub = up_base + __builtin_ctzll(mu);
-        up_done = true;
-      } else {
-        up_base += 64;
-      }
-    }
-    if (!dn_done) {
-      if (md) {
-        pl_lb = dn_base - __builtin_ctzll(md);
-        dn_done = true;
-      } else {
-        dn_base -= 64;
-      }
-    }
-    if (up_done && dn_done) break;
-  }
-  const float q_right = AVG[pl_ub];
-  LT_BSTAMP(4) // walk
-  float out = -FLT_MAX; // maximum over the valid lags outside [pl_lb, pl_ub)
-  const int width = pl_ub - pl_lb;
-  if (width <= 64) {
-    // A thread whose maximum lies outside the lobe contributes it as it is (its other lags are not above
-    // it); a thread whose maximum lies inside has its NL lags looked up in the mirror, one per lane.
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) {
-      const bool inside = ti[k] >= pl_lb && ti[k] < pl_ub;
-      if (!inside && tv[k] > out) out = tv[k]; // (a thread without a maximum holds -FLT_MAX, lag INT_MAX)
-      unsigned long long owners = __ballot(inside);
-      while (owners) {
-        const int t = __builtin_ctzll(owners) + 64 * k;
-        owners &= owners - 1;
-        const int lag = t + lane * NT;
-        if (lane < NL && (lag < pl_lb || lag >= pl_ub) && lag < kNLags) {
-          const float v = AVG[lag];
-          if (v > out) out = v;
-        }
-      }
-    }
-    out = wave_max_f(out);
-  } else {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int lag = tid + i * NT;
-      if ((lag < pl_lb || lag >= pl_ub) && lag < kNLags && ema[i] > out) out = ema[i];
-    }
-    out = wave_max_f(out);
-    if (lane == 0) wave_sl[tid >> 6] = out;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) {
-      const float o = wave_sl[k];
-      if (o > out) out = o;
-    }
-    __syncthreads(); // bs.sl may be rewritten by the next wide lobe
-  }
-  LT_BSTAMP(5) // side lobes
-  float sl = (pl_lb == 0) ? q_left : out, sr = (kNLags - pl_ub <= 0) ? q_right : out;
-  const float side = sl > sr ? sl : sr;
-  SearchResult r;
-  r.peak_pos = __builtin_amdgcn_readfirstlane(peak);
-  r.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value)));
-  r.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(peak_value / side)));
-  return r;
-}
-#undef LT_BSTAMP
-
-// copy the FFT twiddles and the filter spectrum of one root into LDS (2 x 8 KB)
-__device__ __forceinline__ void load_filter_lds(v2f *tw, v2f *spec, const DeviceTables *__restrict__ tab, int n_id_2)
-{
-  for (int i = threadIdx.x; i < fft::kN; i += blockDim.x) {
-    tw[i] = v2f{tab->fft_tw[i].re, tab->fft_tw[i].im};
-    spec[i] = v2f{tab->pss_spec[n_id_2][i].re, tab->pss_spec[n_id_2][i].im};
-  }
 }
 
 // ---- pieces of the tracked-emit path.  Every sum is evaluated in the oracle's operation order
@@ -1075,7 +515,6 @@ __device__ __forceinline__ void sss_m0m1_wave(const v2f *Y, const LdsTables &lt_
   corr = sss_corr(Y, 1, s_rot ^ lt_.c1_mask ^ rot31(lt_.z_mask, r.m0 % 8), half);
   r.m1 = first_max31_wave(corr, &r.m1_value);
 }
-__device__ __forceinline__ void sss_m0m1_wave(Scratch &sc, const LdsTables &lt_, SssResult &r) { sss_m0m1_wave(sc.Y, lt_, r); }
 
 // sss_impl::work after the CP decision: FFT-128 of the SSS symbol, m0/m1 search, N_id_1 (one wave,
 // Y = 62 bins of LDS scratch owned by that wave)
@@ -1088,23 +527,6 @@ __device__ __forceinline__ void sss_after_cp_wave(const v2f *S, int cp, const Ld
   sss_fft128_wave(S + sss_idx, lt_.tw128, Y);
   sss_m0m1_wave(Y, lt_, r);
   r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
-}
-
-// sss_impl::work body after the tag check (lib/sss_impl.cc:102-150) on S = corrected half-frame
-// samples [480, 960) in LDS, executed by ONE wave (no block barrier inside): CP decision, FFT-128 of
-// the SSS symbol, m0/m1 search, N_id_1.  Its results feed nothing but the record and the CP
-// averages, both owned by that wave.
-__device__ __forceinline__ SssResult sss_stage_wave(const v2f *S, const LdsTables &lt_, const DeviceTables *__restrict__ tab,
-                                                   float &m_norm_avg, float &m_ext_avg, Scratch &sc)
-{
-  SssResult r;
-  r.cp = cp_detect_wave(S, m_norm_avg, m_ext_avg);
-  const int cp_len = (r.cp == LT_CP_NORM) ? 9 : 32;                 // srslte_sync_set_cp
-  const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len - kSssBase; // lib/sss_impl.cc:110
-  sss_fft128_wave(S + sss_idx, lt_.tw128, sc.Y);
-  sss_m0m1_wave(sc, lt_, r);
-  r.n_id_1 = sss_n_id_1(tab, (uint32_t)r.m0, (uint32_t)r.m1);
-  return r;
 }
 
 } // namespace lt

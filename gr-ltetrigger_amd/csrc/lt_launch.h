@@ -10,37 +10,48 @@
 
 namespace lt {
 
-struct ChainLaunch {
-  const void *iq;     // device, [n_channels][ch_stride] cf32
-  int64_t n_samples;
+// One pass of the batched path over a chunk (lt_batch_run / lt_batch_push): plan, scan + resolve per segment,
+// per-chain kernel, per-record kernels, history.
+struct RunLaunch {
+  const void *iq;     // device, [n_channels][ch_stride] cf32: the chunk
   int64_t ch_stride;
-  int n_channels;
-  void *state;        // device, ChainState[n_channels*3]
-  lt_record *recs;    // device, [n_channels*3][rec_cap]
-  int rec_cap;
-  int *rec_count;     // device, [n_channels*3]
-  void *out_hf;       // device or null, [n_channels*3][out_cap][9600] cf32
-  int out_cap;
-  const DeviceTables *tab; // device
-  float psr_threshold;
-  int track_after;
-  int track_every;
-  float *metric = nullptr;        // device, [3][n_channels][metric_ch_stride]: bulk + replay mode when set
-  int64_t metric_ch_stride = 0;
-  int64_t metric_root_stride = 0;
-  float *edge = nullptr;          // device, [3][n_channels][max_windows][256]: grid edge lags (bulk + replay mode)
-  int64_t edge_ch_stride = 0;
-  int64_t edge_root_stride = 0;
-  hipEvent_t ev_metric_done = nullptr; // optional: recorded after the lag-metric kernel / after the edge kernel
-  hipEvent_t ev_edge_done = nullptr;
-  hipEvent_t ev_replay_done = nullptr; // ... / after the replay kernel (the per-record post-pass kernels follow)
-  void *cp_scratch = nullptr;     // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics (bulk + replay mode)
-  int n_cus = 256;      // compute units of the device (grid of the persistent metric kernel)
-  int ablate = 0;       // diagnostics only
-  void *prof = nullptr; // diagnostics only: 8 x uint64 on the device
+  int64_t t0;         // absolute stream position of iq[.][0]
+  int64_t n;          // samples in the chunk
+  const void *hist = nullptr; // device, [n_channels][hist_stride] cf32: the hist_len samples in front of t0
+  int64_t hist_stride = 0;
+  int64_t hist_len = 0;
+  void *hist_new = nullptr;   // device: where the history for the next chunk goes (hist_len_new samples per channel)
+  int64_t hist_len_new = 0;
+  int flush = 1;      // the stream ends with this chunk
+  int n_channels = 0;
+  void *state = nullptr;      // device, ChainState[n_channels*3]
+  lt_record *recs = nullptr;  // device, [n_channels*3][rec_cap]
+  int rec_cap = 0;
+  int *rec_count = nullptr;   // device, [n_channels*3]
+  void *out_hf = nullptr;     // device or null, [n_channels*3][out_cap][9600] cf32
+  int out_cap = 0;
+  const DeviceTables *tab = nullptr; // device
+  float psr_threshold = 0.f;
+  int track_after = 16;
+  int track_every = 8;
+  int scan = 1;               // 0: every chain goes through the per-chain kernel
+  void *jobs = nullptr;       // device, ScanJob[n_channels*3]
+  int *n_jobs = nullptr;      // device
+  void *parts = nullptr;      // device, StripPartial[n_channels*3][parts_windows][12]
+  int parts_windows = 0;
+  int seg_first = 2;          // windows in the first scan segment (cells present from the start fire right away)
+  int seg_len = 32;           // windows in the later segments
+  void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics
+  hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
+  hipEvent_t ev_chain_done = nullptr;
 };
 
-hipError_t launch_chain(const ChainLaunch &L, hipStream_t stream);
+hipError_t launch_run(const RunLaunch &R, hipStream_t stream);
+// every chain back to stream position 0 (lt_batch_run: the chunk is a capture of its own)
+hipError_t launch_rebase(void *state, int n_chains, hipStream_t stream);
+int call_reach();
+int scan_job_bytes();
+int strip_partial_bytes(); // per (chain, window)
 size_t chain_state_bytes();
 size_t chain_state_avg_offset();
 

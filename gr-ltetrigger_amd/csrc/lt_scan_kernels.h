@@ -188,4 +188,168 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   }
 }
 
+// ---------------------------------------------------------------- plan: which chains does the scan serve?
+// One thread per channel.  A chain is eligible when it is idle (not tracking, score 0, no tracking_lost pending:
+// every call searches, and a miss moves on by exactly 9600 samples, lib/pss_impl.cc:163-182,217) and at
+// least one window fits into the chunk.  Chains of a channel at the same stream position share a job.
+struct PlanArgs {
+  ChainState *state;
+  ScanJob *jobs;
+  int *n_jobs;       // zeroed before the launch
+  int *rec_count;    // [n_channels*3]: zeroed here
+  int n_channels;
+  int rec_cap;
+  int64_t t1;        // absolute end of the chunk
+  int flush;
+  int enable;        // 0: no chain goes to the scan (lt_batch_set_mode 0)
+  int max_windows;   // room in the partial-result array
+  int call_reach;    // kCallReach (lt_chain_kernel.h)
+};
+
+__global__ void lt_plan_kernel(PlanArgs a)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.n_channels) return;
+  int nwin[3];
+  int64_t pos[3];
+  for (int r = 0; r < 3; ++r) {
+    ChainState *st = a.state + c * 3 + r;
+    a.rec_count[c * 3 + r] = 0;
+    st->scan_job = -1;
+    st->scan_live = 0;
+    st->scan_done = 0;
+    st->scan_seg0 = 0;
+    pos[r] = st->pos;
+    const bool idle = !st->is_tracking && st->score == 0 && !st->tracking_lost;
+    int64_t n = 0;
+    if (idle && a.enable) {
+      // calls that may start in this chunk (the per-chain kernel applies the same rule)
+      const int64_t room = a.t1 - pos[r] - (a.flush ? kHalfFrame : a.call_reach);
+      n = room >= 0 ? room / kHalfFrame + 1 : 0;
+      if (n > a.rec_cap) n = a.rec_cap;
+      if (n > a.max_windows) n = a.max_windows;
+    }
+    nwin[r] = (int)n;
+  }
+  for (int r = 0; r < 3; ++r) {
+    if (nwin[r] <= 0) continue;
+    bool leader = true;
+    for (int q = 0; q < r; ++q) leader = leader && !(nwin[q] > 0 && pos[q] == pos[r]);
+    if (!leader) continue;
+    const int j = atomicAdd(a.n_jobs, 1);
+    ScanJob job;
+    job.pos0 = pos[r];
+    job.channel = c;
+    job.n_windows = nwin[r];
+    job.roots = 0;
+    for (int q = r; q < 3; ++q)
+      if (nwin[q] > 0 && pos[q] == pos[r]) {
+        job.roots |= 1 << q;
+        a.state[c * 3 + q].scan_job = j;
+        a.state[c * 3 + q].scan_live = 1;
+      }
+    job.rec0[0] = job.rec0[1] = job.rec0[2] = 0;
+    a.jobs[j] = job;
+  }
+}
+
+// ---------------------------------------------------------------- resolve: partials -> records, in call order
+// One wave per chain, one lane per window (64 at a time): every lane combines the 12 partials of its window
+// (resolve_window); the first window that fires -- PSR over the threshold -- or that the strips could not
+// resolve ends the chain's time in the scan.  The windows before it are misses: general_work searched, did
+// not emit and consumed 9600 samples (lib/pss_impl.cc:163-182, 217); their records are written here.
+struct ResolveArgs {
+  ChainState *state;
+  const ScanJob *jobs;
+  const StripPartial *parts;
+  int64_t parts_windows;
+  lt_record *recs;
+  int rec_cap;
+  int *rec_count;
+  int w_begin, w_end; // the scan segment just run
+  float psr_threshold;
+  int track_every;
+};
+
+__global__ __launch_bounds__(64) void lt_resolve_kernel(ResolveArgs a)
+{
+  const int chain = blockIdx.x, lane = threadIdx.x;
+  ChainState *st = a.state + chain;
+  if (!st->scan_live) return;
+  const ScanJob job = a.jobs[st->scan_job];
+  const int w_end = a.w_end < job.n_windows ? a.w_end : job.n_windows;
+  if (a.w_begin >= w_end) return;
+  const StripPartial *parts = a.parts + (int64_t)chain * a.parts_windows * kStrips;
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  float psr_max = st->psr_max, last_psr = st->psr;
+  int last_peak = st->peak_pos;
+  uint32_t psr_i = st->psr_i;
+  const float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
+  const int call_base = st->n_calls - a.w_begin; // window k of the job is call call_base + k (records start at 0 each run)
+  int fired_at = -1;
+  for (int base = a.w_begin; base < w_end; base += 64) {
+    const int k = base + lane;
+    const bool valid = k < w_end;
+    WindowResult r;
+    r.peak_pos = 0; r.peak_value = 0.f; r.psr = 0.f; r.exact = true;
+    if (valid) r = resolve_window(parts + (int64_t)k * kStrips);
+    const bool fire = valid && (!r.exact || r.psr > a.psr_threshold);
+    const unsigned long long fm = __ballot(fire);
+    const int first = fm ? __builtin_ctzll(fm) : 64;
+    const bool miss = valid && lane < first;
+    // d_psr_max over the calls so far (if (psr > psr_max) psr_max = psr), as an inclusive prefix maximum
+    float pm = miss ? r.psr : -FLT_MAX;
+    if (!(pm == pm)) pm = -FLT_MAX; // a NaN never raises the maximum
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(pm, d);
+      if (lane >= d) pm = fmaxf(pm, o);
+    }
+    const float my_max = fmaxf(psr_max, pm);
+    if (miss) {
+      lt_record rec;
+      rec.in_pos = job.pos0 + (int64_t)k * kHalfFrame; rec.out_pos = -1; rec.channel = chain / 3; rec.n_id_2 = chain % 3;
+      rec.call_idx = call_base + k; rec.flags = LT_F_SEARCHED; rec.peak_pos = r.peak_pos; rec.score = 0;
+      rec.psr = r.psr; rec.peak_value = r.peak_value; rec.cfo = 0.f; rec.mean_cfo = 0.f;
+      rec.m_norm_avg = m_norm_avg; rec.m_ext_avg = m_ext_avg; rec.m0_value = 0.f;
+      rec.m1_value = 0.f; rec.m0 = -1; rec.m1 = -1; rec.n_id_1 = -1; rec.cell_id = -1;
+      rec.psr_max = my_max; rec.timer = a.track_every;
+      recs[k] = rec;
+      st->psr_data[(psr_i + (uint32_t)(k - base)) % kMovingAvgSz] = r.psr; // d_psr_data ring (lib/pss_impl.cc:166)
+    }
+    const int n_miss = first < 64 ? first : (w_end - base < 64 ? w_end - base : 64);
+    if (n_miss > 0) {
+      psr_max = __shfl(my_max, n_miss - 1);
+      last_psr = __shfl(r.psr, n_miss - 1);
+      last_peak = __shfl(r.peak_pos, n_miss - 1);
+      psr_i += (uint32_t)n_miss;
+    }
+    if (first < 64) {
+      fired_at = base + first;
+      break;
+    }
+  }
+  if (lane == 0) {
+    const int done = fired_at >= 0 ? fired_at : w_end; // windows of the job turned into records so far
+    const int n_new = done - a.w_begin;
+    st->pos = job.pos0 + (int64_t)done * kHalfFrame;
+    st->n_calls += n_new;
+    st->psr_i = psr_i;
+    st->psr_max = psr_max;
+    if (n_new > 0) {
+      st->psr = last_psr;
+      st->peak_pos = last_peak;
+      st->timer = a.track_every;
+    }
+    st->scan_done = done;
+    a.rec_count[chain] = done;
+    if (fired_at >= 0) {
+      st->scan_live = 0;          // the per-chain kernel takes over at window `fired_at` ...
+      st->scan_seg0 = a.w_begin;  // ... from the average as it was before this segment (avg[ema_sel])
+    } else {
+      st->ema_sel ^= 1;           // the scan has left the average after window w_end - 1 in the other buffer
+    }
+  }
+}
+
 } // namespace lt

@@ -166,26 +166,43 @@ int lt_batch_create(lt_batch **b, int device, int n_channels, int64_t max_sample
 void lt_batch_free(lt_batch *b);
 /* All chains back to their constructor state. */
 int lt_batch_reset(lt_batch *b);
-/* Execution strategy of lt_batch_run: 1 (default) = one bulk kernel computes the position-independent
- * lag metric of every channel for all three roots, a light per-chain kernel replays the windows;
- * 0 = everything fused in the per-chain kernel.  Same records (lag metric equal to ~1e-6).  Mode 1 needs
- * 12 B of HBM per sample for the lag metric; a batch that cannot get it falls back to mode 0 for good. */
+/* Execution strategy: 1 (default) = the searches of all idle chains run as one chip-wide grid scan (exponential
+ * averages in registers, strip-wise peak search), and a per-chain kernel executes general_work call by call
+ * for the chains that fire, build a score or track; 0 = the per-chain kernel serves every chain.  Same
+ * arithmetic on the same strips either way: identical records.  Everything either mode needs is allocated by
+ * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
+int lt_batch_get_mode(lt_batch *b);
+/* The grid scan runs in segments of windows; a chain that fires leaves the scan at the end of its segment.
+ * first = windows in the first segment (default 2: cells present from the start of a capture fire at once),
+ * later = windows in every following segment (default 32). */
+int lt_batch_set_scan_segments(lt_batch *b, int first, int later);
 /* downlink_trigger_c.set_psr_threshold fan-out (python/downlink_trigger_c.py:63-69) */
 int lt_batch_set_psr_threshold(lt_batch *b, float threshold);
-/* Run every chain over iq = [n_channels][n_samples] cf32 (channel-major, contiguous).
+/* Run every chain over iq = [n_channels][n_samples] cf32 (channel-major, contiguous), a capture of its own:
+ * positions restart at sample 0 of `iq`, with the chain state left by the previous run unless
+ * lt_batch_reset is called.
  * iq_on_device != 0: iq is a device pointer on the batch's device and the work is enqueued on
  * `hip_stream` (a hipStream_t; NULL = the batch's own stream) without host synchronisation.
  * iq_on_device == 0: iq is a host pointer, staged through the batch's device buffer.
  * A chain stops when fewer than 9600 new samples remain or an emission would read past the
- * capture (reference quirk q1 normalised).  Each run starts at sample 0 of `iq`
- * with the chain state left by the previous run unless lt_batch_reset is called. */
+ * capture (reference quirk q1 normalised). */
 int lt_batch_run(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples,
                  void *hip_stream);
+/* The same for a stream fed in chunks of any size (an SDR ring): the chunk continues where the previous one
+ * ended -- set_history(9600) / consume_each of lib/pss_impl.cc:81,160,195: every chain resumes at its own
+ * position, the library keeps the samples a chain may still need from earlier chunks, and a call starts only
+ * once everything it could touch has arrived (the next call's 9600-sample window and the half-frame a peak
+ * anywhere in it would emit: 18365 samples).  Records carry absolute stream positions; the cuts do not show in
+ * them.  end_of_stream != 0: no more samples follow -- the chains run on under lt_batch_run's rule.
+ * lt_batch_reset starts a new stream. */
+int lt_batch_push(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samples, int end_of_stream,
+                  void *hip_stream);
 /* Wait for the last run; copy records out: recs = [n_channels*3][cap_per_chain],
  * counts = [n_channels*3]; chain index = channel*3 + N_id_2. */
 int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts);
-/* Upper bound on records per chain for n_samples (a call consumes >= 8640 samples). */
+/* Upper bound on records per chain and run for chunks of n_samples (a call consumes >= 8640 samples; a chunk
+ * may also finish calls left over from the one before). */
 int64_t lt_batch_record_capacity(int64_t n_samples);
 /* Optional capture of the emitted (CFO-corrected) half-frames = the pss block's output stream
  * (lib/pss_impl.cc:188-193,204).  max_per_chain = 0 disables.  Read back with
@@ -194,10 +211,9 @@ int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain);
 int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, int64_t *count);
 /* Device time of the chain kernel of the last run, in milliseconds (HIP events on the run's stream). */
 int lt_batch_last_kernel_ms(lt_batch *b, float *ms);
-/* The same, per kernel, of the run `runs_back` runs ago (0 = the last one; the last 8 are kept):
- * ms[0] = lag-metric kernel, ms[1] = grid edge-lag kernel, ms[2] = per-chain (replay, or fused)
- * kernel, ms[3] = the per-record post-pass kernels (CP length, SSS); only ms[2] is non-zero in fused
- * mode. */
+/* The same, per stage, of the run `runs_back` runs ago (0 = the last one; the last 8 are kept):
+ * ms[0] = plan + grid scan + resolve (all segments), ms[1] = 0, ms[2] = per-chain kernel, ms[3] = the
+ * per-record kernels (CP length, SSS) and the history copy. */
 int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4]);
 
 /* ------------------------------------------------------------------ decimating FIR */
