@@ -5,11 +5,12 @@ Workload (BASELINE.json configs[2]; with N GPUs it is configs[3] scaled, 64 chan
 each rank owns 64 independent 1.92 Msps capture channels of 1 s each, built from the four
 bundled fixtures (decimated to 1.92 Msps, seeded rotation, looped, AWGN 20 dB, every 8th
 channel noise only), resident in HBM before the timed region.  One step = one pass of the
-PSS->SSS path over the whole batch (state reset + lag-metric, edge-lag and replay kernels).  Channels are
-independent, so ranks never exchange data; torch.distributed is used for the barrier and the
+PSS->SSS path over the whole batch (state reset + grid scan + per-chain kernel + per-record kernels).
+Channels are independent, so ranks never exchange data; torch.distributed is used for the barrier and the
 max-over-ranks of the wall time only.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...          # WORLD_SIZE unset: starts the N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -17,6 +18,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,9 +33,15 @@ FS = 1_920_000
 FIXTURES = [("lte_frame_6prb_cellid_123", 1, 123), ("lte_frame_25prb_cellid_124", 4, 124),
             ("lte_frame_50prb_cellid_125", 8, 125), ("lte_frame_100prb_cellid_369", 16, 369)]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-ALGO_BYTES_PER_SAMPLE = 8.0  # SURVEY 8(d), whole path: cf32 read once, all three roots + SSS served from it
-# per kernel of the bulk + replay execution (DESIGN.md "Kernels"): what each one must move at least
-METRIC_BYTES_PER_SAMPLE = 8.0 + 3 * 4.0  # lt_metric_kernel: cf32 in, |conv|^2 of three roots out
+ALGO_BYTES_PER_SAMPLE = 8.0  # cf32 read exactly once, all three roots + SSS served from it
+STAGES = ("grid_scan", None, "lt_chain_kernel", "per_record")  # lt_batch_phase_ms slots
+# kernels rocprofv3 sees per stage (profiles/traffic.json is keyed by kernel name)
+STAGE_KERNELS = {"grid_scan": ("lt_plan_kernel", "lt_scan_kernel", "lt_resolve_kernel"),
+                 "lt_chain_kernel": ("lt_chain_kernel",),
+                 "per_record": ("lt_cfo_kernel", "lt_cfo_ring_kernel", "lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")}
+INT_FIELDS = ("in_pos", "out_pos", "flags", "peak_pos", "score", "m0", "m1", "n_id_1", "cell_id", "timer")
+EXACT_FLOAT_FIELDS = ("cfo", "mean_cfo", "m_norm_avg", "m_ext_avg", "m0_value", "m1_value")
+METRIC_FIELDS = ("psr", "peak_value", "psr_max")
 
 
 def base_frames(lt):
@@ -82,7 +91,38 @@ def cells_found(lt, recs, n_channels):
     return found
 
 
-def main():
+def records_equal(got, want):
+    """GPU records against the oracle's: index / flag fields and everything downstream of the lag metric bit for
+    bit, the lag-metric quantities to 1e-4 (the parity bar of tests/test_gpu_parity.py)."""
+    if len(got) != len(want):
+        return False
+    ok = True
+    for f in INT_FIELDS:
+        ok = ok and bool(np.array_equal(got[f], want[f]))
+    for f in EXACT_FLOAT_FIELDS:
+        ok = ok and bool(np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)))
+    for f in METRIC_FIELDS:
+        ok = ok and bool(np.allclose(got[f], want[f], rtol=1e-4, atol=0, equal_nan=True))
+    return ok
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as children (torch.distributed.run) before this
+    process has touched a GPU, pass their output through, exit with their code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -92,17 +132,59 @@ def main():
     ap.add_argument("--snr-db", type=float, default=20.0)
     ap.add_argument("--cpu-channels", type=int, default=64, help="channels in the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--mode", type=int, default=1, help="lt_batch_set_mode (1 = grid scan + per-chain kernel)")
+    ap.add_argument("--scan-segments", default="", help="first,later: lt_batch_set_scan_segments (windows per scan segment)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the cpu_baseline (0 = the box's CPU share for one GPU: min(available, 16))")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / aggregation plumbing only (gloo, no GPU, no hot path): for the CPU test suite")
+    return ap.parse_args(argv)
+
+
+def dry_run(args, rank, world):
+    """No GPU work at all: every rank reports a fixed fake time, rank 0 prints the line.  Exercises the
+    self-launch, the rendezvous, the max-over-ranks and the JSON contract on a CPU-only box."""
+    import torch
+    import torch.distributed as dist
+    from ltetrigger_amd import sharding
+    if world > 1:
+        dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    n = int(round(args.seconds * FS))
+    mine = sharding.channel_range(rank, world, args.channels)
+    elapsed = sharding.max_over_ranks(dist, torch, 1.0 + 0.5 * rank, dev)
+    ch_sum, = sharding.sum_over_ranks(dist, torch, [len(mine)], dev)
+    if rank == 0:
+        print(json.dumps({"metric": "IQ Msamp/s through PSS+SSS detect", "value": 0.0, "unit": "Msamp/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "none (dry run: no hot-path work was done)", "dry_run": True,
+                          "config": {"workload": "dry run", "channels_total": int(ch_sum), "samples_per_channel": n},
+                          "slowest_rank_s": elapsed}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
     import ltetrigger_amd as lt
+    from ltetrigger_amd import sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the hot path)")
     torch.cuda.set_device(local_rank)
@@ -110,7 +192,6 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from ltetrigger_amd import sharding
     n_ch = args.channels
     n = int(round(args.seconds * FS))
     frames = base_frames(lt)
@@ -121,7 +202,10 @@ def main():
     torch.cuda.synchronize()
 
     batch = lt.Batch(n_ch, n, psr_threshold=4.0, device=local_rank)
-    # a dedicated non-default stream: the kernel, the events that time it and the state reset all
+    batch.set_mode(args.mode)
+    if args.scan_segments:
+        batch.set_scan_segments(*[int(v) for v in args.scan_segments.split(",")])
+    # a dedicated non-default stream: the kernels, the events that time them and the state reset all
     # go onto it (a NULL stream handle would select the batch's own stream inside the library)
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
@@ -154,10 +238,17 @@ def main():
     elapsed = time.perf_counter() - t0
 
     elapsed = sharding.max_over_ranks(dist, torch, elapsed, dev)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    # per kernel: the library's own HIP events around each launch, of the last (up to 8) timed steps
+    if args.steps <= 0:
+        if rank == 0:
+            print(json.dumps({"metric": "IQ Msamp/s through PSS+SSS detect", "value": None, "unit": "Msamp/s",
+                              "n_gpus": world, "steps": 0, "warmup": args.warmup, "error": "no timed steps"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # per stage: the library's own HIP events on the launch stream, of the last (up to 8) timed steps
     phases = np.array([batch.phase_ms(k) for k in range(min(args.steps, 8))], dtype=np.float64)
-    phase_ms = phases.mean(axis=0) if len(phases) else np.full(4, np.nan)
+    phase_ms = phases.mean(axis=0)
 
     # correctness of what was timed: cell_id match on this rank's channels
     recs = batch.collect()
@@ -169,38 +260,35 @@ def main():
 
     if rank == 0:
         value = sharding.aggregate_msamp_per_s(world, n_ch, n, args.steps, elapsed)
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    traffic = json.load(f).get("kernels", {})
-            except (OSError, ValueError):
-                traffic = {}
-        # algorithmic bytes per launch of each kernel: the metric kernel reads every sample once
-        # and writes three floats per sample; the edge kernel reads 256 samples and writes 3 x 253 floats per
-        # window; the replay kernel reads the 9473 interior lags + 253 edge lags of every window it searches
-        # and the 128-sample PSS symbol of every tracked half-frame, and writes one 96-byte record per call
-        n_win = n // 9600
+        algo_bytes = ALGO_BYTES_PER_SAMPLE * n_ch * n  # per launch and GPU
+        # what each stage has to read and write at least ("kernel I/O", not the path's algorithmic bytes):
+        # the scan reads every sample of the searched windows once and writes 12 x 32 B of partial results per
+        # (chain, window) plus one 96-byte record per miss; the per-chain kernel reads the 9600-sample window of
+        # every call it searches and the 128-sample PSS symbol of every tracked half-frame and writes a record per
+        # call; the per-record kernels read 480 + 128 samples per tracked half-frame and rewrite the records
         searched = sum(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
         sss_ran = sum(int(((r["flags"] & lt.F_SSS_RAN) != 0).sum()) for r in recs)
+        misses = sum(int((r["flags"] == lt.F_SEARCHED).sum()) for r in recs)
         calls = sum(len(r) for r in recs)
-        algo = {
-            "lt_metric_kernel": METRIC_BYTES_PER_SAMPLE * n_ch * n,
-            "lt_edge_kernel": float(n_ch * n_win) * (256 * 8 + 3 * 253 * 4),
-            "lt_chain_kernel": searched * 9726 * 4.0 + sss_ran * 128 * 8.0 + calls * 96.0,
-            # lt_cp_kernel + lt_cp_scan_kernel + lt_sss_kernel: 480 + 128 samples per tracked half-frame, the
-            # record read and written once each
-            "post_pass": sss_ran * (480 + 128) * 8.0 + calls * 2 * 96.0,
+        n_win = n // 9600
+        io = {
+            "grid_scan": algo_bytes + 3.0 * n_ch * n_win * 12 * 32 + misses * 96.0,
+            "lt_chain_kernel": (searched - misses) * 9600 * 8.0 + sss_ran * 128 * 8.0 + (calls - misses) * 96.0,
+            "per_record": sss_ran * (480 + 128) * 8.0 + calls * 2 * 96.0,
         }
+        traffic, traffic_src = load_traffic()
         kernels = []
-        for name, ms in zip(("lt_metric_kernel", "lt_edge_kernel", "lt_chain_kernel", "post_pass"), phase_ms):
-            if not ms > 0:
+        for name, ms in zip(STAGES, phase_ms):
+            if name is None or not ms > 0:
                 continue
-            t = traffic.get(name, {}).get("hbm_bytes_per_launch")
-            kernels.append({"kernel": name, "ms": round(float(ms), 4), "algorithmic_bytes_per_launch": algo[name],
-                            "achieved": round(algo[name] / (ms * 1e-3) / 1e9, 2), "traffic": t})
+            t = None
+            if traffic is not None:
+                t = sum(traffic.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in STAGE_KERNELS[name])
+            kernels.append({"stage": name, "kernels": list(STAGE_KERNELS[name]), "ms": round(float(ms), 4),
+                            "kernel_io_bytes_per_launch": io[name],
+                            "kernel_io_gbs": round(io[name] / (ms * 1e-3) / 1e9, 2), "traffic": t})
         dom = max(kernels, key=lambda k: k["ms"])
+        traffic_total = sum(k["traffic"] for k in kernels) if traffic is not None else None
         out = {
             "metric": "IQ Msamp/s through PSS+SSS detect",
             "value": round(value, 3),
@@ -208,7 +296,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -221,68 +309,145 @@ def main():
                 "channels_per_gpu": n_ch,
                 "samples_per_channel": n,
                 "psr_threshold": 4.0,
+                "execution_mode": batch.mode(),
                 "sharding": "independent channels per rank, no collective on the data path",
             },
             "cell_id_match_rate": match_rate,
             "realtime_factor": round(value * 1e6 / (world * n_ch * FS), 2),
-            # the dominant kernel = the one with the largest measured duration
+            # algorithmic bytes = 8 B per input sample, whatever a kernel spills on top.
+            # achieved = those bytes / the dominant stage's time (the stage with the largest measured duration)
             "roofline": {
                 "bound": "hbm",
-                "kernel": dom["kernel"],
-                "achieved": dom["achieved"],
+                "kernel": dom["stage"],
+                "kernel_ms": dom["ms"],
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "achieved": round(algo_bytes / (dom["ms"] * 1e-3) / 1e9, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(dom["achieved"] / HBM_PEAK_GBS, 5),
-                "traffic": dom["traffic"],
-                "kernel_ms": dom["ms"],
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "kernels": kernels,
-                # the whole path against its own floor (every sample read once, 8 B)
+                "frac": round(algo_bytes / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                # the whole path (all stages of a step, device time) against the same 8 B per sample
                 "path_ms": round(kernel_ms, 4),
-                "path_achieved": round(ALGO_BYTES_PER_SAMPLE * n_ch * n / (kernel_ms * 1e-3) / 1e9, 2),
+                "path_achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 2),
+                "path_frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                # HBM bytes per launch from the PMC counters of a profiled run of this same command
+                "traffic": traffic_total,
+                "traffic_ratio": round(traffic_total / algo_bytes, 3) if traffic_total else None,
+                "traffic_source": traffic_src,
+                "kernels": kernels,
             },
         }
+        if not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(torch, lt, iq, n_ch, n, local_rank)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lt, iq, recs, min(args.cpu_channels, n_ch), value)
+            out["cpu_baseline"] = cpu_baseline(lt, iq, recs, min(args.cpu_channels, n_ch), value / world, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(lt, iq, gpu_recs, n_ch, gpu_value):
+def load_traffic():
+    """profiles/traffic.json: per-kernel HBM bytes per launch from rocprofv3 PMC passes over this workload
+    (tools/pmc_traffic.sh).  Used only if it was taken with the kernels that exist now."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tpath) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    k = t.get("kernels", {})
+    if "lt_scan_kernel" not in k:
+        return None, "profiles/traffic.json predates the current kernels"
+    return k, f"profiles/traffic.json ({t.get('taken', 'undated')}; {t.get('method', '')})"
+
+
+def end_to_end(torch, lt, iq, n_ch, n, device):
+    """SURVEY 8(d) end-to-end figure: pinned host buffer -> hipMemcpyAsync -> kernels -> records back to the host,
+    two batches on two streams so that the copy of one pass overlaps the kernels of the other."""
+    host = torch.empty((n_ch, n), dtype=torch.complex64, pin_memory=True)
+    host.copy_(iq)
+    torch.cuda.synchronize()
+    hnp = host.numpy()
+    batches = [lt.Batch(n_ch, n, psr_threshold=4.0, device=device) for _ in range(2)]
+    passes = 4
+    for b in batches:  # warm-up: staging buffers, first-touch
+        b.reset()
+        b.run_host(hnp)
+        b.collect()
+    t0 = time.perf_counter()
+    for i in range(passes):
+        b = batches[i & 1]
+        if i >= 2:
+            b.collect()  # records of the pass this batch ran two passes ago
+        b.reset()
+        b.run_host(hnp)  # H2D + kernels, asynchronous on the batch's own stream
+    for b in batches:
+        b.collect()
+    dt = time.perf_counter() - t0
+    for b in batches:
+        b.close()
+    return {"value": round(n_ch * n * passes / dt / 1e6, 3), "unit": "Msamp/s", "passes": passes,
+            "ms_per_pass": round(dt / passes * 1e3, 3),
+            "h2d_gbs": round(n_ch * n * 8.0 * passes / dt / 1e9, 2),
+            "what": "pinned host -> hipMemcpyAsync -> kernels -> records D2H, double-buffered over two streams; one GPU"}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(lt, iq, gpu_recs, n_ch, gpu_value_per_gpu, threads=0):
     """The CPU oracle (restatement of the srsLTE-18.06.1 algorithm the reference runs: FFT-9728
     convolution per root, three independent chains per channel) timed on this box's host cores
     on the first n_ch channels of the same batch; also used to check the GPU records."""
     from oracle import oracle as O
-    cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
+    nproc = os.cpu_count() or 1
+    try:
+        nproc_avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        nproc_avail = nproc
+    # a GPU box hands one GPU's job 16 of the host's cores, whatever os.cpu_count() sees; more threads than that
+    # only oversubscribe them (--cpu-threads overrides)
+    cores = threads if threads > 0 else min(nproc_avail, 16)
     x = iq[:n_ch].cpu().numpy()
     O.lib()
-    passes = 3  # ~20 s of CPU work in total; the fastest pass is reported
+    passes = 3  # the fastest pass is reported
     dt = float("inf")
     for _ in range(passes):
         t0 = time.perf_counter()
         want = O.batch_run(x, nthreads=cores)
         dt = min(dt, time.perf_counter() - t0)
-    same = True
-    for c in range(n_ch * 3):
-        g, w = gpu_recs[c], want[c]
-        if len(g) != len(w):
-            same = False
-            continue
-        for f in ("in_pos", "out_pos", "flags", "peak_pos", "score", "m0", "m1", "n_id_1", "cell_id"):
-            same = same and bool(np.array_equal(g[f], w[f]))
+    same = all(records_equal(gpu_recs[c], want[c]) for c in range(n_ch * 3))
+    # single core: a smaller sample of the same batch, one thread
+    n1 = min(n_ch, 8)
+    t0 = time.perf_counter()
+    O.batch_run(x[:n1], nthreads=1)
+    dt1 = time.perf_counter() - t0
     value = x.size / dt / 1e6
     return {
         "value": round(value, 3),
         "unit": "Msamp/s",
         "cores": cores,
         "kind": "port",
+        "what": "restatement of the srsLTE 18.06.1 algorithm (oracle/lte_oracle.c), not srsLTE itself",
         "sample": f"first {n_ch} channels x {x.shape[1]} samples of the same batch, 3 chains each, "
                   f"OpenMP over chains on {cores} threads, best of {passes} passes ({dt:.2f} s wall each, "
-                  f"~{dt * cores * passes:.0f} core-seconds in total)",
+                  f"~{dt * cores * passes + dt1:.0f} core-seconds in total)",
+        "single_core": {"value": round(x[:n1].size / dt1 / 1e6, 3), "unit": "Msamp/s",
+                        "sample": f"first {n1} channels, one thread, one pass ({dt1:.2f} s)"},
+        "nproc": nproc,
+        "nproc_available": nproc_avail,
+        "threads_rule": "--cpu-threads" if threads > 0 else "min(nproc_available, 16): the GPU box's CPU share for one GPU",
+        "cpu_model": cpu_model(),
         "records_match_gpu": same,
-        "gpu_over_cpu": round(gpu_value / value, 1),
+        "gpu_over_cpu": round(gpu_value_per_gpu / value, 1),
     }
 
 

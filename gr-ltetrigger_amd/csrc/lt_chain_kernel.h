@@ -1,8 +1,9 @@
 // Per-chain kernel: pss_impl::general_work (lib/pss_impl.cc:155-223) call by call for one (channel, N_id_2)
 // chain per workgroup, from wherever the chain stands: a chain the grid scan (lt_scan_kernels.h) has carried up
 // to the window that fired, a chain that is building its score or tracking, or -- with the scan switched
-// off (lt_batch_set_mode 0) -- any chain at all.  One record per call; the sss block's CP / SSS results are
-// added to the records afterwards by the per-record kernels in lt_kernels.hip.
+// off (lt_batch_set_mode 0) -- any chain at all.  One record per call.  Everything the emitted half-frames go
+// through -- CFO estimate and correction of the pss block, CP decision and SSS of the sss block -- feeds records
+// only, never the state machine, and is added afterwards by the per-record kernels in lt_kernels.hip.
 //
 // 12 waves, wave s = strip s of the window being searched (lt_scan.h): it fetches the strip's 1024 samples,
 // runs the forward transform, multiplies by the root's filter spectrum, transforms back and keeps the strip's
@@ -36,8 +37,6 @@ struct ChainArgs {
   lt_record *recs;     // [n_channels*3][rec_cap]
   int rec_cap;
   int *rec_count;      // [n_channels*3]: in = records the resolver wrote, out = records of the run
-  v2f *out_hf;         // nullable: [n_channels*3][out_cap][9600]
-  int out_cap;
   const DeviceTables *tab;
   float psr_threshold;
   int track_after;
@@ -71,21 +70,20 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
   }
 }
 
-// lag metric + exponential average of the window at absolute position w0 (every wave its strip)
-__device__ __forceinline__ void chain_window_ema(ChainLds &L, const Capture &cap, int64_t w0, int w, int lane, float (&ema)[kStripRegs])
+// srslte_pss_find_pss on the window whose strip samples are in x (strip_load).  resolve = false: lag metric and
+// exponential average only (a window the scan has already turned into a record).  Contains workgroup
+// barriers; `buf` alternates between calls.
+__device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane,
+                                                     float (&ema)[kStripRegs], int &buf, bool resolve)
 {
-  fft::c32 x[16];
-  strip_load(cap, w0, w, lane, x);
   fft::c32 *e = L.E + w * fft::kScratchW;
   strip_fft<false>(lane, x, L.TW1, L.TW2, e);
   strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
-}
-
-// srslte_pss_find_pss on the window at w0.  Contains workgroup barriers; `buf` alternates between calls.
-__device__ __forceinline__ SearchResult chain_search(ChainLds &L, const Capture &cap, int64_t w0, int w, int lane,
-                                                     float (&ema)[kStripRegs], int &buf)
-{
-  chain_window_ema(L, cap, w0, w, lane, ema);
+  SearchResult out;
+  out.peak_pos = 0;
+  out.peak_value = 0.f;
+  out.psr = 0.f;
+  if (!resolve) return out;
   StripPartial p;
   strip_resolve(ema, w, lane, p);
   StripPartial *parts = L.parts[buf];
@@ -93,7 +91,6 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, const Capture 
   if (lane == 0) parts[w] = p;
   __syncthreads();
   const WindowResult r = resolve_window(parts);
-  SearchResult out;
   out.peak_pos = __builtin_amdgcn_readfirstlane(r.peak_pos);
   out.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.peak_value)));
   out.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.psr)));
@@ -155,14 +152,8 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, const Capture 
 __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
 {
   __shared__ ChainLds L;
-  __shared__ LdsTables ltab;
   __shared__ float psr_data[kMovingAvgSz];
-  __shared__ float cfo_data[kMovingAvgSz];
-  __shared__ v2f RAW[kSymbolSz];
-  __shared__ v2f RAWb[kChainWaves][kSymbolSz]; // the PSS symbol of each wave's half-frame (batched tracked emits)
-  __shared__ float batch_cfo[kChainWaves];
-  __shared__ float sh_cfo, sh_mean_cfo;
-  constexpr int NT = kChainThreads, NW = kChainWaves;
+  constexpr int NT = kChainThreads;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,108 +170,105 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   cap.n = a.n;
   cap.hist_len = a.hist ? a.hist_len : 0;
   const int64_t t1 = a.t0 + a.n;
-  const DeviceTables *__restrict__ tab = a.tab;
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
 
   // ---- load state
   float ema[kStripRegs];
   float *avg = st->avg[st->ema_sel];
   strip_ema_load(avg, w, lane, ema);
-  for (int i = tid; i < kMovingAvgSz; i += NT) {
-    psr_data[i] = st->psr_data[i];
-    cfo_data[i] = st->cfo_data[i];
-  }
-  chain_lds_init(L, tab, n_id_2);
-  load_lds_tables(ltab, tab, n_id_2);
+  for (int i = tid; i < kMovingAvgSz; i += NT) psr_data[i] = st->psr_data[i];
+  chain_lds_init(L, a.tab, n_id_2);
   int64_t pos = st->pos;
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
-  uint32_t psr_i = st->psr_i, cfo_i = st->cfo_i;
-  int n_emits = 0;
+  uint32_t psr_i = st->psr_i;
   float psr = st->psr, psr_max = st->psr_max;
-  const float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg; // owned by lt_cp_scan_kernel; records carry the run's start values until then
   int nrec = a.rec_count[chain]; // the misses the resolver has turned into records
   const int call_base = st->n_calls - nrec;
+  int n_emits = 0;
   int buf = 0;
   __syncthreads();
 
-  // ---- a chain coming from the scan: its average is the one from before the scan segment in which it
-  // fired; bring it up to the window that fired (the resolver has written those windows' records)
+  // ---- a chain coming from the scan: its average is the one from before the scan segment in which it fired;
+  // the windows from there up to the one that fired (the resolver has written their records) are run through
+  // the lag metric and the average once more, by the same search call as every other window
+  int redo_k = 0, redo_end = 0;
+  int64_t redo_pos0 = 0;
   if (scan_job >= 0) {
-    const int64_t pos0 = a.jobs[scan_job].pos0;
-    for (int k = st->scan_seg0; k < st->scan_done; ++k) chain_window_ema(L, cap, pos0 + (int64_t)k * kHalfFrame, w, lane, ema);
+    redo_pos0 = a.jobs[scan_job].pos0;
+    redo_k = st->scan_seg0;
+    redo_end = st->scan_done;
   }
-
   auto can_call = [&](int64_t p) { return a.flush ? p + kHalfFrame <= t1 : p + kCallReach <= t1; };
-  while (can_call(pos) && nrec < a.rec_cap) {
+  // the samples of the window searched next are fetched one search ahead (a search is 12 x 2 transforms on one
+  // CU; the memory latency of its 77 KB would otherwise sit in front of every one of them)
+  fft::c32 xpf[16];
+  int64_t pf_pos = INT64_MIN;
+
+  // One record: everything the sss side adds (CFO, CP, SSS: lt_kernels.hip, per record) starts out empty.
+  auto put_record = [&](int idx, int64_t in_pos, int64_t out_pos, uint32_t flags, int used_peak, int sc, float ps, float pv, float pmax, int tm) {
+    lt_record r;
+    r.in_pos = in_pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
+    r.call_idx = call_base + idx; r.flags = flags; r.peak_pos = used_peak; r.score = sc;
+    r.psr = ps; r.peak_value = pv; r.cfo = 0.f; r.mean_cfo = 0.f;
+    r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+    r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+    r.psr_max = pmax; r.timer = tm;
+    recs[idx] = r;
+  };
+
+  for (;;) {
+    const bool redo = redo_k < redo_end;
+    if (!redo && !(can_call(pos) && nrec < a.rec_cap)) break;
     // ---- tracked chain between two searches (lib/pss_impl.cc:163-214 with timer > 0): the next `timer` calls
     // neither search nor change the score; each emits the half-frame at its input position (peak_pos is 960
-    // since the emit of the last search).  Their CFO estimates are independent, so they run one per wave:
-    //   A  stage the PSS symbol and estimate the CFO                               (parallel)
-    //   B  ring mean with this call's and the earlier calls' estimates entered     (parallel, exact)
-    if (is_tracking && timer > 0 && !tracking_lost && peak_pos == kSlotLen && psr > a.psr_threshold) {
+    // since the emit of the last search).  Nothing of what they compute (CFO, CP, SSS) feeds the state machine:
+    // one record per call, one lane each.
+    if (!redo && is_tracking && timer > 0 && !tracking_lost && peak_pos == kSlotLen && psr > a.psr_threshold) {
       int nb = timer;
       while (nb > 0 && !can_call(pos + (int64_t)(nb - 1) * kHalfFrame)) --nb;
       if (a.rec_cap - nrec < nb) nb = a.rec_cap - nrec;
-      for (int done = 0; done < nb; done += NW) {
-        const int nr = (nb - done < NW) ? nb - done : NW;
-        const bool act = w < nr;
-        const int idx = done + w; // call within the batch
+      for (int idx = tid; idx < nb; idx += NT) {
         const int64_t hf0 = pos + (int64_t)idx * kHalfFrame;
-        float c = 0.f, mc = 0.f;
-        if (act) {
-          for (int i = lane; i < kSymbolSz; i += 64) RAWb[w][i] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + i);
-          c = cfo_estimate_wave(ltab.taps, RAWb[w]);
-          if (lane == 0) batch_cfo[w] = c;
-        }
-        __syncthreads();
-        const uint32_t slot0 = cfo_i % kMovingAvgSz;
-        float ring_new = 0.f;
-        if (tid < nr) ring_new = batch_cfo[tid];
-        v2f *out = nullptr;
-        if (act) {
-          mc = moving_avg_wave(cfo_data, cfo_i + (uint32_t)w + 1u, slot0, batch_cfo, (uint32_t)w + 1u);
-          if (a.out_hf && n_emits + idx < a.out_cap) out = a.out_hf + ((int64_t)chain * a.out_cap + n_emits + idx) * kHalfFrame;
-        }
-        __syncthreads(); // every wave has read the ring
-        if (tid < nr) cfo_data[(slot0 + tid) % kMovingAvgSz] = ring_new;
-        if (act) {
-          // rotation, CP decision and SSS feed nothing here: lt_cp_kernel / lt_cp_scan_kernel / lt_sss_kernel
-          if (lane == 0) {
-            lt_record r;
-            r.in_pos = hf0; r.out_pos = hf0; r.channel = channel; r.n_id_2 = n_id_2;
-            r.call_idx = call_base + nrec + idx; r.flags = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
-            r.peak_pos = kSlotLen; r.score = score;
-            r.psr = psr; r.peak_value = 0.f; r.cfo = c; r.mean_cfo = mc;
-            r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
-            r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
-            r.psr_max = psr_max; r.timer = timer - 1 - idx;
-            recs[nrec + idx] = r;
-          }
-          if (out) {
-            const float freq = -mc / (float)kSymbolSz;
-            const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-            for (int i = lane; i < kHalfFrame; i += 64) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
-          }
-        }
-        cfo_i += (uint32_t)nr;
+        put_record(nrec + idx, hf0, hf0, LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING, kSlotLen, score, psr, 0.f,
+                   psr_max, timer - 1 - idx);
       }
-      if (nb > 0) {
-        timer -= nb;
-        nrec += nb;
-        n_emits += nb;
-        pos += (int64_t)nb * kHalfFrame;
-        continue;
-      }
-      break; // the next call does not fit into this chunk
+      timer -= nb;
+      nrec += nb;
+      n_emits += nb;
+      pos += (int64_t)nb * kHalfFrame;
+      continue;
     }
 
     uint32_t flags = 0;
     float peak_value = 0.f;
     // ---- lib/pss_impl.cc:163-172
-    if (!is_tracking || timer == 0) {
+    if (redo || !is_tracking || timer == 0) {
+      const int64_t wpos = redo ? redo_pos0 + (int64_t)redo_k * kHalfFrame : pos;
+      // (the lane index is made opaque per iteration: otherwise the compiler hoists every lane-dependent address
+      // and mask of the search out of the loop and spills them across it)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      if (pf_pos != wpos) strip_load(cap, wpos, w, ln, xpf); // (first search of the run, or a chain that re-aligned)
+      fft::c32 x[16];
+#pragma unroll
+      for (int R = 0; R < 16; ++R) x[R] = xpf[R];
+      // next: the following window of the redo, then the chain's own position; after that a miss leads to
+      // pos + 9600, a tracked chain that keeps its timing searches again track_every + 1 half-frames on
+      int64_t npos;
+      if (redo) npos = (redo_k + 1 < redo_end) ? wpos + kHalfFrame : pos;
+      else npos = pos + (int64_t)kHalfFrame * (is_tracking ? a.track_every + 1 : 1);
+      pf_pos = INT64_MIN;
+      if ((redo && redo_k + 1 < redo_end) || can_call(npos)) {
+        pf_pos = npos;
+        strip_load(cap, npos, w, ln, xpf);
+      }
+      const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo);
+      if (redo) {
+        redo_k++;
+        continue;
+      }
       timer = a.track_every;
-      const SearchResult r = chain_search(L, cap, pos, w, lane, ema, buf);
       peak_pos = r.peak_pos;
       psr = r.psr;
       peak_value = r.peak_value;
@@ -310,15 +298,12 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
       is_tracking = 0;
 #pragma unroll
       for (int t = 0; t < kStripRegs; ++t) ema[t] = 0.f;
-      psr_i = 0;
-      cfo_i = 0;
+      psr_i = 0; // (d_cfo_i restarts too: lt_cfo_ring_kernel sees the tracking_lost tag this call puts on its half-frame)
       tracking_lost = 1;
     }
     if (psr > psr_max) psr_max = psr;
 
     int64_t out_pos = -1, next_pos;
-    float cfo = 0.f, mean_cfo = 0.f;
-
     if (over || tracking_lost) { // ---- lib/pss_impl.cc:184-214
       const int frame_start = peak_pos - kSlotLen;
       peak_pos = kSlotLen;
@@ -327,39 +312,14 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
       next_pos = hf0 + kHalfFrame;
       out_pos = hf0;
       flags |= LT_F_EMITTED;
-      v2f *out = (a.out_hf && n_emits < a.out_cap) ? a.out_hf + ((int64_t)chain * a.out_cap + n_emits) * kHalfFrame : nullptr;
       if (is_tracking) {
-        // CFO estimate on the uncorrected PSS symbol (lib/pss_impl.cc:199-201), ring update and mean_cfo() -- the
-        // chain's only emit-side state.  Rotation of the half-frame, CP decision and SSS feed nothing in this
-        // kernel: lt_cp_kernel / lt_cp_scan_kernel / lt_sss_kernel run them afterwards from the record.
-        if (tid < kSymbolSz) RAW[tid] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + tid);
-        __syncthreads();
-        if (tid < 64) {
-          const float c = cfo_estimate_wave(ltab.taps, RAW);
-          const uint32_t slot = cfo_i % kMovingAvgSz;
-          const float mc = moving_avg_wave(cfo_data, cfo_i + 1, slot, c);
-          if (tid == 0) {
-            cfo_data[slot] = c;
-            sh_cfo = c;
-            sh_mean_cfo = mc;
-          }
-        }
-        __syncthreads();
-        cfo_i++;
-        cfo = sh_cfo;
-        mean_cfo = sh_mean_cfo;
-        if (out) {
-          const float freq = -mean_cfo / (float)kSymbolSz; // srslte_cfo_correct, lib/pss_impl.cc:204
-          const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-          for (int i = tid; i < kHalfFrame; i += NT) out[i] = cfo_rotate(tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
-        }
+        // CFO estimate and correction (lib/pss_impl.cc:199-204), CP decision and SSS (lib/sss_impl.cc:102-150) of
+        // this half-frame: per record, after this kernel
         flags |= LT_F_SSS_RAN;
       } else {
         // tracking lost: tag the half-frame (lib/pss_impl.cc:210-214); sss resets on the tag (lib/sss_impl.cc:91-100)
         flags |= LT_F_TAG_LOST;
         tracking_lost = 0;
-        if (out)
-          for (int i = tid; i < kHalfFrame; i += NT) out[i] = ld_abs(cap, hf0 + i);
       }
       n_emits++;
     } else {
@@ -367,16 +327,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     }
 
     if (is_tracking) flags |= LT_F_TRACKING;
-    if (tid == 0) {
-      lt_record r;
-      r.in_pos = pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
-      r.call_idx = call_base + nrec; r.flags = flags; r.peak_pos = used_peak_pos; r.score = score;
-      r.psr = psr; r.peak_value = peak_value; r.cfo = cfo; r.mean_cfo = mean_cfo;
-      r.m_norm_avg = m_norm_avg; r.m_ext_avg = m_ext_avg; r.m0_value = 0.f;
-      r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
-      r.psr_max = psr_max; r.timer = timer;
-      recs[nrec] = r;
-    }
+    if (tid == 0) put_record(nrec, pos, out_pos, flags, used_peak_pos, score, psr, peak_value, psr_max, timer);
     nrec++;
     pos = next_pos;
   }
@@ -384,15 +335,12 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   // ---- store state
   __syncthreads();
   strip_ema_store(avg, w, lane, ema);
-  for (int i = tid; i < kMovingAvgSz; i += NT) {
-    st->psr_data[i] = psr_data[i];
-    st->cfo_data[i] = cfo_data[i];
-  }
+  for (int i = tid; i < kMovingAvgSz; i += NT) st->psr_data[i] = psr_data[i];
   if (tid == 0) {
     st->pos = pos;
     st->is_tracking = is_tracking; st->score = score; st->timer = timer;
     st->tracking_lost = tracking_lost; st->peak_pos = peak_pos;
-    st->psr_i = psr_i; st->cfo_i = cfo_i;
+    st->psr_i = psr_i;
     st->n_calls = call_base + nrec; st->n_emits += n_emits;
     st->psr = psr; st->psr_max = psr_max;
     a.rec_count[chain] = nrec;
@@ -418,7 +366,9 @@ __global__ __launch_bounds__(kChainThreads) void lt_find_kernel(const v2f *__res
   chain_lds_init(L, tab, n_id_2);
   __syncthreads();
   int buf = 0;
-  const SearchResult r = chain_search(L, cap, 0, w, lane, ema, buf);
+  fft::c32 x[16];
+  strip_load(cap, 0, w, lane, x);
+  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true);
   strip_ema_store(avg, w, lane, ema);
   if (tid == 0) {
     res->peak_pos = r.peak_pos;

@@ -5,8 +5,9 @@
 //                         exponential averages in registers, one forward transform per block shared by the three roots.
 //   lt_chain_kernel (lt_chain_kernel.h) -- one workgroup per chain that fired (or that the scan does not serve):
 //                         pss_impl::general_work call by call (lib/pss_impl.cc:155-223), CFO ring; one lt_record per call.
-//   lt_cp_kernel, lt_cp_scan_kernel, lt_sss_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) of the tracked
-//                         half-frames, per record, afterwards (its results feed records only).
+//   lt_cfo_kernel, lt_cfo_ring_kernel -- CFO estimate and mean_cfo() of the tracked half-frames (lib/pss_impl.cc:199-204),
+//   lt_cp_kernel, lt_cp_scan_kernel, lt_sss_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) on them, lt_hf_kernel -- the
+//                         pss block's output stream (optional capture): all per record, afterwards (they feed records only).
 //   lt_hist_kernel     -- keeps the tail of the chunk for the next lt_batch_push.
 // lt_find_kernel, lt_cfo_*, lt_sync_*  -- single-call forms behind the srslte_* shaped C-ABI.
 // lt_decim_kernel -- decimating FIR in front of the path.
@@ -200,6 +201,158 @@ struct CpArgs {
   const DeviceTables *tab;
   int n_chains;
 };
+
+// ---------------------------------------------------------------- CFO of the tracked half-frames
+// srslte_pss_cfo_compute on the uncorrected PSS symbol of every tracked half-frame (lib/pss_impl.cc:199-201):
+// independent per record, one wave each.
+__global__ __launch_bounds__(256) void lt_cfo_kernel(CpArgs a)
+{
+  __shared__ v2f RAW[4][kSymbolSz];
+  const int chain = blockIdx.x, channel = chain / 3, n_id_2 = chain % 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = blockIdx.y * 4 + w;
+  if (idx >= a.rec_count[chain]) return;
+  lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
+  if (!(rec->flags & LT_F_SSS_RAN)) return;
+  const int64_t hf0 = rec->out_pos;
+  const Capture cap = make_capture(a, channel);
+  for (int i = lane; i < kSymbolSz; i += 64) RAW[w][i] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + i);
+  const float c = cfo_estimate_wave(reinterpret_cast<const v2f *>(a.tab->pss_taps[n_id_2]), RAW[w]);
+  if (lane == 0) rec->cfo = c;
+}
+
+// d_cfo_data ring and mean_cfo() (lib/pss_impl.cc:94-109,200-204) in call order: one wave per chain.  The ring
+// restarts where reset_score cleared d_cfo_i (lib/pss_impl.cc:145): the call that does so tags its half-frame
+// tracking_lost, and d_cfo_i is 0 whenever a chain is not tracking.
+//
+// compute_moving_avg sums the first min(d_cfo_i, 200) ring entries in index order in double.  While the
+// exponents of all entries seen since the ring restarted span at most 20 binades (no subnormals), every partial
+// sum of any subset is a multiple of the smallest ulp below 2^53 of them: no addition rounds, so the sum is
+// the same in any order -- and it can be carried along (add the new entry, drop the one it overwrites) instead
+// of being formed anew for every call.  Outside that window the sum runs in ring order (moving_avg_wave).
+__global__ __launch_bounds__(64) void lt_cfo_ring_kernel(CpArgs a)
+{
+  __shared__ float ring[kMovingAvgSz];
+  const int chain = blockIdx.x, lane = threadIdx.x;
+  ChainState *st = a.state + chain;
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  const int count = a.rec_count[chain];
+  for (int i = lane; i < kMovingAvgSz; i += 64) ring[i] = st->cfo_data[i];
+  uint32_t cfo_i = st->cfo_i;
+  // the entries the previous runs left behind: exponent range and (if it is narrow) their exact sum
+  uint32_t emin = 255u, emax = 0u;
+  bool narrow = true;
+  double acc = 0.0;
+  {
+    const uint32_t npts = cfo_i < (uint32_t)kMovingAvgSz ? cfo_i : (uint32_t)kMovingAvgSz;
+    double part = 0.0;
+    uint32_t lmin = 255u, lmax = 0u;
+    bool sub = false;
+    for (uint32_t i = lane; i < npts; i += 64) {
+      const float v = ring[i];
+      const uint32_t bits = __float_as_uint(v) & 0x7fffffffu, e = bits >> 23;
+      if (bits) {
+        sub = sub || e == 0u;
+        lmin = e < lmin ? e : lmin;
+        lmax = e > lmax ? e : lmax;
+      }
+      part += (double)v;
+    }
+    emin = (uint32_t)wave_min_i((int)lmin);
+    emax = (uint32_t)wave_max_i((int)lmax);
+    narrow = !__ballot(sub) && (emax == 0u || (emax - emin <= 20u && emax < 255u));
+    part += lane_xor_d<1>(part); part += lane_xor_d<2>(part); part += lane_xor_d<4>(part);
+    part += lane_xor_d<8>(part); part += lane_xor_d<16>(part); part += lane_xor_d<32>(part);
+    acc = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)), __builtin_amdgcn_readfirstlane(__double2loint(part)));
+  }
+  for (int base = 0; base < count; base += 64) {
+    const int i = base + lane;
+    const uint32_t flags = i < count ? recs[i].flags : 0u;
+    const float c = (flags & LT_F_SSS_RAN) ? recs[i].cfo : 0.f;
+    const unsigned long long ran = __ballot((flags & LT_F_SSS_RAN) != 0), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
+    unsigned long long events = ran | lost;
+    float mine = 0.f;
+    while (events) {
+      const int j = __builtin_ctzll(events);
+      events &= events - 1;
+      if ((lost >> j) & 1) {
+        cfo_i = 0;
+        emin = 255u; emax = 0u; narrow = true; acc = 0.0;
+      }
+      if ((ran >> j) & 1) {
+        const float cj = rlane(c, j);
+        const uint32_t slot = cfo_i % kMovingAvgSz;
+        const uint32_t npts = cfo_i + 1 < (uint32_t)kMovingAvgSz ? cfo_i + 1 : (uint32_t)kMovingAvgSz;
+        const uint32_t bits = __float_as_uint(cj) & 0x7fffffffu, e = bits >> 23;
+        if (bits) {
+          if (e == 0u) narrow = false;
+          emin = e < emin ? e : emin;
+          emax = e > emax ? e : emax;
+          if (emax - emin > 20u || emax >= 255u) narrow = false;
+        }
+        float mc;
+        if (narrow) {
+          if (cfo_i >= (uint32_t)kMovingAvgSz) acc -= (double)ring[slot]; // the entry this call overwrites
+          acc += (double)cj;
+          mc = (float)(acc / (double)npts);
+        } else {
+          mc = moving_avg_wave(ring, cfo_i + 1, slot, cj);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ring[slot] = cj;
+        __builtin_amdgcn_wave_barrier();
+        cfo_i++;
+        if (lane == j) mine = mc;
+      }
+    }
+    if (i < count && (flags & LT_F_SSS_RAN)) recs[i].mean_cfo = mine;
+  }
+  for (int i = lane; i < kMovingAvgSz; i += 64) st->cfo_data[i] = ring[i];
+  if (lane == 0) st->cfo_i = cfo_i;
+}
+
+// The pss block's output stream (optional capture, lt_batch_enable_halfframes): every emitted half-frame,
+// CFO-corrected when tracking (lib/pss_impl.cc:188-193,204).  One workgroup per record.
+struct HfArgs {
+  const v2f *iq;
+  int64_t ch_stride;
+  const v2f *hist;
+  int64_t hist_stride;
+  int64_t t0, n, hist_len;
+  const lt_record *recs;
+  int rec_cap;
+  const int *rec_count;
+  v2f *out_hf; // [n_chains][out_cap][9600]
+  int out_cap;
+  const DeviceTables *tab;
+};
+__global__ __launch_bounds__(256) void lt_hf_kernel(HfArgs a)
+{
+  __shared__ int n_before;
+  const int chain = blockIdx.x, idx = blockIdx.y, tid = threadIdx.x;
+  if (idx >= a.rec_count[chain]) return;
+  const lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  const lt_record rec = recs[idx];
+  if (!(rec.flags & LT_F_EMITTED)) return;
+  if (tid == 0) n_before = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int i = tid; i < idx; i += 256) cnt += (recs[i].flags & LT_F_EMITTED) ? 1 : 0;
+  if (cnt) atomicAdd(&n_before, cnt);
+  __syncthreads();
+  const int slot = n_before;
+  if (slot >= a.out_cap) return;
+  v2f *out = a.out_hf + ((int64_t)chain * a.out_cap + slot) * kHalfFrame;
+  const Capture cap = make_capture(a, chain / 3);
+  if (rec.flags & LT_F_SSS_RAN) {
+    const float freq = -rec.mean_cfo / (float)kSymbolSz; // srslte_cfo_correct, lib/pss_impl.cc:204
+    const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+    for (int i = tid; i < kHalfFrame; i += 256) out[i] = cfo_rotate(a.tab->cexptab, phase_inc, i, ld_abs(cap, rec.out_pos + i));
+  } else {
+    for (int i = tid; i < kHalfFrame; i += 256) out[i] = ld_abs(cap, rec.out_pos + i);
+  }
+}
 
 __global__ __launch_bounds__(256) void lt_cp_kernel(CpArgs a)
 {
@@ -426,8 +579,8 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     ChainArgs c;
     c.iq = iq; c.ch_stride = R.ch_stride; c.hist = hist; c.hist_stride = R.hist_stride; c.t0 = R.t0; c.n = R.n;
     c.hist_len = R.hist_len; c.flush = R.flush; c.n_channels = R.n_channels; c.state = state; c.jobs = jobs;
-    c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count; c.out_hf = reinterpret_cast<v2f *>(R.out_hf);
-    c.out_cap = R.out_cap; c.tab = R.tab; c.psr_threshold = R.psr_threshold; c.track_after = R.track_after;
+    c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
+    c.tab = R.tab; c.psr_threshold = R.psr_threshold; c.track_after = R.track_after;
     c.track_every = R.track_every;
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
   }
@@ -442,9 +595,19 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     q.iq = iq; q.ch_stride = R.ch_stride; q.hist = hist; q.hist_stride = R.hist_stride; q.t0 = R.t0; q.n = R.n;
     q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;
     const dim3 per_record((unsigned)n_chains, (unsigned)((R.rec_cap + 3) / 4));
+    hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, stream, c);
+    hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, stream, c);
     hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, stream, c);
     hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, stream, c);
     hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, stream, q);
+    if (R.out_hf && R.out_cap > 0) {
+      if (R.rec_cap > 65535) return hipErrorInvalidValue;
+      HfArgs h;
+      h.iq = iq; h.ch_stride = R.ch_stride; h.hist = hist; h.hist_stride = R.hist_stride; h.t0 = R.t0; h.n = R.n;
+      h.hist_len = R.hist_len; h.recs = R.recs; h.rec_cap = R.rec_cap; h.rec_count = R.rec_count;
+      h.out_hf = reinterpret_cast<v2f *>(R.out_hf); h.out_cap = R.out_cap; h.tab = R.tab;
+      hipLaunchKernelGGL(lt_hf_kernel, dim3((unsigned)n_chains, (unsigned)R.rec_cap), dim3(256), 0, stream, h);
+    }
   }
   // ---- history for the next chunk
   if (R.hist_new && R.hist_len_new > 0) {

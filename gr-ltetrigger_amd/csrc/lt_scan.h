@@ -235,13 +235,25 @@ __device__ __forceinline__ void strip_load(const Capture &c, int64_t w0, int s, 
       }
     }
   } else {
+    // window across the start of the chunk (the first windows of a lt_batch_push), or across its end: window
+    // sample i lies in the chunk for i in [lo_c, hi_c), in the history for i in [lo_h, lo_c), nowhere else.
+    // Wave-uniform 64-bit bases, 32-bit lane offsets.
+    const int64_t d = c.t0 - w0; // window index of the chunk's first sample
+    const int lo_c = (int)(d < -kHalfFrame ? -kHalfFrame : d > 2 * kHalfFrame ? 2 * kHalfFrame : d);
+    const int64_t dh = d + c.n, dl = d - c.hist_len;
+    const int hi_c = (int)(dh < -kHalfFrame ? -kHalfFrame : dh > 2 * kHalfFrame ? 2 * kHalfFrame : dh);
+    const int lo_h = (int)(dl < -kHalfFrame ? -kHalfFrame : dl > 2 * kHalfFrame ? 2 * kHalfFrame : dl);
+    const v2f *__restrict__ pc = c.iq - d;                                  // pc[i] = window sample i, from the chunk
+    const v2f *__restrict__ ph = c.hist ? c.hist + (c.hist_len - d) : c.iq; // ph[i] = window sample i, from the history
 #pragma unroll
     for (int R = 0; R < 16; ++R) {
       const int i = i0 + 64 * R;
-      const bool ok = i >= 0 && i < kHalfFrame;
-      const v2f v = ld_abs(c, w0 + (ok ? i : 0));
+      const bool in_win = i >= 0 && i < kHalfFrame;
+      const bool in_c = in_win && i >= lo_c && i < hi_c, in_h = in_win && i >= lo_h && i < lo_c;
+      const v2f *p = in_h ? ph + i : pc + (in_c ? i : (int)d); // (neither: the chunk's first sample, dropped below)
+      const v2f v = *p;
       v2f z = {0.f, 0.f};
-      x[R] = ok ? v : z;
+      x[R] = (in_c || in_h) ? v : z;
     }
   }
 }

@@ -133,15 +133,17 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     strip_load(cap, job.pos0 + (int64_t)a.w_begin * kHalfFrame, strip, lane, x);
     if (n_w > 1) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + 1) * kHalfFrame, strip, lane, xn);
     for (int k = 0; k < n_w; ++k) {
+      int ln = lane; // (opaque per iteration: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
+      asm volatile("" : "+v"(ln));
       // the root waves have taken window k - 1: the exchange area is free
       while (__hip_atomic_load(&sync_taken[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_roots * k) __builtin_amdgcn_s_sleep(1);
       LT_LDS_ORDER;
-      strip_fft_ab(lane, x, TW1, TW2, e);
+      strip_fft_ab(ln, x, TW1, TW2, e);
       LT_LDS_ORDER;
       if (lane == 0) __hip_atomic_store(&sync_ready[g], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int R = 0; R < 16; ++R) x[R] = xn[R];
-      if (k + 2 < n_w) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + k + 2) * kHalfFrame, strip, lane, xn);
+      if (k + 2 < n_w) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + k + 2) * kHalfFrame, strip, ln, xn);
     }
   } else if (active) {
 #ifdef LT_ROOT_PRIO
@@ -159,21 +161,23 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #define LT_PSTAMP(i)
 #endif
     for (int k = 0; k < n_w; ++k) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
       while (__hip_atomic_load(&sync_ready[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
       LT_LDS_ORDER;
       LT_PSTAMP(0) // waiting for the forward wave
-      fft::fft1024w_stageC<false>(lane, x, e_fwd); // x = the block's spectrum
+      fft::fft1024w_stageC<false>(ln, x, e_fwd); // x = the block's spectrum
       LT_LDS_ORDER;
       if (lane == 0) __hip_atomic_fetch_add(&sync_taken[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       LT_PSTAMP(1) // last forward stage
 #ifdef LT_SCAN_PROF
-      strip_root_update_prof(strip, lane, x, SPEC[root], TW1, TW2, e, ema, pr, tp);
+      strip_root_update_prof(strip, ln, x, SPEC[root], TW1, TW2, e, ema, pr, tp);
 #else
-      strip_root_update(strip, lane, x, SPEC[root], TW1, TW2, e, ema);
+      strip_root_update(strip, ln, x, SPEC[root], TW1, TW2, e, ema);
 #endif
       StripPartial p;
 #ifndef LT_ABL_NO_RESOLVE
-      strip_resolve(ema, strip, lane, p);
+      strip_resolve(ema, strip, ln, p);
 #else
       p.m1 = ema[3]; p.p1 = 0; p.s = ema[5]; p.lb = p.ub = 0; p.a0 = 0.f; p.flags = 0; p.pad = 0;
 #endif

@@ -96,3 +96,25 @@ def test_two_gloo_ranks_equal_one_rank():
     iq, _ = bench.make_channels(torch, _frames(), 4, N, 0, 20.0, torch.device("cpu"))
     one = [float(np.abs(iq[c].numpy()).sum()) for c in range(4)]
     assert one == two[0][2] + two[1][2]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) starts two ranks itself and
+    prints exactly one JSON line for the job -- here in its dry-run form (gloo, no GPU, no hot-path work)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["dry_run"] is True
+    assert out["config"]["channels_total"] == 128      # 64 per rank, every channel owned once
+    assert out["slowest_rank_s"] == 1.5                # max over ranks
+    # under a launcher the same file must not start ranks again
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
