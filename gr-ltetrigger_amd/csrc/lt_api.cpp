@@ -149,8 +149,7 @@ struct lt_batch {
   int64_t hf_cap = 0;
   void *d_jobs = nullptr;    // grid scan: ScanJob[n_channels*3]
   int *d_njobs = nullptr;
-  void *d_parts = nullptr;   // grid scan: StripPartial[n_channels*3][parts_windows][12]
-  int parts_windows = 0;
+  void *d_parts = nullptr;   // grid scan: the partial results of a round, per chain
   void *d_cp = nullptr;      // per-record CP metrics, [n_channels*3][rec_cap] x 16 B
   lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
   int hist_sel = 0;
@@ -515,7 +514,6 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   b->params = *params;
   b->rec_cap = (int)lt_batch_record_capacity(max_samples);
   b->hist_cap = history_capacity();
-  b->parts_windows = (int)((max_samples + b->hist_cap) / LT_HALF_FRAME_LEN + 2);
   rc = get_tables(device, &b->tab);
   if (rc) { delete b; return rc; }
   // Everything a run needs is allocated here, so that no run can fail -- or change its execution strategy -- for
@@ -527,7 +525,7 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_count, sizeof(int) * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_jobs, (size_t)lt::scan_job_bytes() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::strip_partial_bytes() * nchains * (size_t)b->parts_windows);
+  if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::scan_parts_bytes_per_chain() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)16 * nchains * (size_t)b->rec_cap);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
@@ -655,7 +653,6 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.jobs = b->d_jobs;
   R.n_jobs = b->d_njobs;
   R.parts = b->d_parts;
-  R.parts_windows = b->parts_windows;
   R.seg_first = b->seg_first;
   R.seg_len = b->seg_len;
   R.cp_scratch = b->d_cp;
@@ -780,7 +777,8 @@ int lt_batch_get_mode(lt_batch *b) { return b ? b->mode : fail(LT_ERROR_INVALID_
 
 int lt_batch_set_scan_segments(lt_batch *b, int first, int later)
 {
-  if (!b || first < 1 || later < 1) return fail(LT_ERROR_INVALID_INPUTS, "segment lengths must be >= 1 window");
+  if (!b || first < 1 || later < 1 || first > lt::scan_max_round() || later > lt::scan_max_round())
+    return fail(LT_ERROR_INVALID_INPUTS, "windows per scan round must be in [1, %d]", lt::scan_max_round());
   b->seg_first = first;
   b->seg_len = later;
   return LT_OK;

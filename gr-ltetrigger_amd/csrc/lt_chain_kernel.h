@@ -33,7 +33,6 @@ struct ChainArgs {
                        // when everything it could touch is in the chunk
   int n_channels;
   ChainState *state;   // [n_channels*3], index channel*3 + n_id_2
-  const ScanJob *jobs;
   lt_record *recs;     // [n_channels*3][rec_cap]
   int rec_cap;
   int *rec_count;      // [n_channels*3]: in = records the resolver wrote, out = records of the run
@@ -159,9 +158,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chain = blockIdx.x, channel = chain / 3, n_id_2 = chain % 3;
   ChainState *st = a.state + chain;
-  // a chain the scan has carried through all the windows it may search in this run has nothing left to do
-  const int scan_job = st->scan_job;
-  if (scan_job >= 0 && st->scan_live) return;
+  if (st->run_done) return; // the resolver has seen the chain stop for this run
 
   Capture cap;
   cap.iq = a.iq + (int64_t)channel * a.ch_stride;
@@ -171,35 +168,40 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   cap.hist_len = a.hist ? a.hist_len : 0;
   const int64_t t1 = a.t0 + a.n;
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  auto can_call = [&](int64_t p) { return a.flush ? p + kHalfFrame <= t1 : p + kCallReach <= t1; };
 
-  // ---- load state
+  int64_t pos = st->pos;
+  int nrec = a.rec_count[chain]; // the calls the scan rounds have turned into records
+  // a chain the scan rounds have carried as far as the chunk allows has nothing left to do in this run -- unless its
+  // average is still described through windows of this chunk (pre_n): those samples will be gone by the next one
+  if (!(can_call(pos) && nrec < a.rec_cap) && st->pre_n == 0) return;
+
+  // ---- load state.  The average is avg[ema_sel] (or all zeros after srslte_pss_reset) run through the pre_n
+  // windows of a scan round the chain did not follow to its end: brought up to date before the first search,
+  // by the same search call as every other window.
   float ema[kStripRegs];
   float *avg = st->avg[st->ema_sel];
-  strip_ema_load(avg, w, lane, ema);
+  if (st->ema_zero) {
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+  } else {
+    strip_ema_load(avg, w, lane, ema);
+  }
+  int redo_k = 0;
+  const int redo_end = st->pre_n;
+  const int64_t redo_pos0 = st->pre_pos;
+  const int redo_stride = st->pre_stride;
   for (int i = tid; i < kMovingAvgSz; i += NT) psr_data[i] = st->psr_data[i];
   chain_lds_init(L, a.tab, n_id_2);
-  int64_t pos = st->pos;
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
   uint32_t psr_i = st->psr_i;
   float psr = st->psr, psr_max = st->psr_max;
-  int nrec = a.rec_count[chain]; // the misses the resolver has turned into records
   const int call_base = st->n_calls - nrec;
   int n_emits = 0;
   int buf = 0;
+  bool searched = false; // the registers hold the chain's average (a search has run)
   __syncthreads();
-
-  // ---- a chain coming from the scan: its average is the one from before the scan segment in which it fired;
-  // the windows from there up to the one that fired (the resolver has written their records) are run through
-  // the lag metric and the average once more, by the same search call as every other window
-  int redo_k = 0, redo_end = 0;
-  int64_t redo_pos0 = 0;
-  if (scan_job >= 0) {
-    redo_pos0 = a.jobs[scan_job].pos0;
-    redo_k = st->scan_seg0;
-    redo_end = st->scan_done;
-  }
-  auto can_call = [&](int64_t p) { return a.flush ? p + kHalfFrame <= t1 : p + kCallReach <= t1; };
   // the samples of the window searched next are fetched one search ahead (a search is 12 x 2 transforms on one
   // CU; the memory latency of its 77 KB would otherwise sit in front of every one of them)
   fft::c32 xpf[16];
@@ -218,8 +220,12 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   };
 
   for (;;) {
-    const bool redo = redo_k < redo_end;
-    if (!redo && !(can_call(pos) && nrec < a.rec_cap)) break;
+    const bool callable = can_call(pos) && nrec < a.rec_cap;
+    // the windows the average still has to go through come first: before the first search, or -- if no call fits
+    // into this chunk any more -- before the kernel ends
+    const bool search_due = !(is_tracking && timer > 0 && !tracking_lost && peak_pos == kSlotLen && psr > a.psr_threshold) && (!is_tracking || timer == 0);
+    const bool redo = redo_k < redo_end && (search_due || !callable);
+    if (!callable && !redo) break;
     // ---- tracked chain between two searches (lib/pss_impl.cc:163-214 with timer > 0): the next `timer` calls
     // neither search nor change the score; each emits the half-frame at its input position (peak_pos is 960
     // since the emit of the last search).  Nothing of what they compute (CFO, CP, SSS) feeds the state machine:
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     float peak_value = 0.f;
     // ---- lib/pss_impl.cc:163-172
     if (redo || !is_tracking || timer == 0) {
-      const int64_t wpos = redo ? redo_pos0 + (int64_t)redo_k * kHalfFrame : pos;
+      const int64_t wpos = redo ? redo_pos0 + (int64_t)redo_k * redo_stride * kHalfFrame : pos;
       // (the lane index is made opaque per iteration: otherwise the compiler hoists every lane-dependent address
       // and mask of the search out of the loop and spills them across it)
       int ln = lane;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
       // next: the following window of the redo, then the chain's own position; after that a miss leads to
       // pos + 9600, a tracked chain that keeps its timing searches again track_every + 1 half-frames on
       int64_t npos;
-      if (redo) npos = (redo_k + 1 < redo_end) ? wpos + kHalfFrame : pos;
+      if (redo) npos = (redo_k + 1 < redo_end) ? wpos + (int64_t)redo_stride * kHalfFrame : pos;
       else npos = pos + (int64_t)kHalfFrame * (is_tracking ? a.track_every + 1 : 1);
       pf_pos = INT64_MIN;
       if ((redo && redo_k + 1 < redo_end) || can_call(npos)) {
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
         strip_load(cap, npos, w, ln, xpf);
       }
       const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo);
+      searched = true;
       if (redo) {
         redo_k++;
         continue;
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
 
   // ---- store state
   __syncthreads();
-  strip_ema_store(avg, w, lane, ema);
+  if (searched && redo_k >= redo_end) strip_ema_store(avg, w, lane, ema); // (else: the average is described as before)
   for (int i = tid; i < kMovingAvgSz; i += NT) st->psr_data[i] = psr_data[i];
   if (tid == 0) {
     st->pos = pos;
@@ -343,6 +350,10 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     st->psr_i = psr_i;
     st->n_calls = call_base + nrec; st->n_emits += n_emits;
     st->psr = psr; st->psr_max = psr_max;
+    if (searched && redo_k >= redo_end) {
+      st->ema_zero = 0;
+      st->pre_n = 0;
+    }
     a.rec_count[chain] = nrec;
   }
 }

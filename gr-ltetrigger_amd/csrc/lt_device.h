@@ -45,14 +45,23 @@ struct ChainState {
   float psr_max;        // d_psr_max
   float m_norm_avg;     // srslte_sync_t::M_norm_avg
   float m_ext_avg;      // srslte_sync_t::M_ext_avg
-  int32_t ema_sel;      // which of avg[2] is current (the grid scan writes the other one, lt_scan_kernels.h)
-  int32_t scan_live;    // this run: the chain is (still) served by the grid scan
-  int32_t scan_job;     // this run: its job, -1 = none
-  int32_t scan_done;    // this run: windows of the job the resolver has turned into records
-  int32_t scan_seg0;    // this run: first window of the scan segment avg[ema_sel] is the state before
+  // ---- the exponential average and how the grid scan hands it on (lt_scan_kernels.h).  avg[ema_sel] is a valid
+  // state of conv_output_avg; the chain's current average is that state run through the pre_n windows
+  // pre_pos + k * pre_stride * 9600 (windows of a scan round whose tail the chain did not follow), or all
+  // zeros when ema_zero is set (srslte_pss_reset).  A scan round writes into the other two buffers.
+  int32_t ema_sel;
+  int32_t ema_zero;
+  int32_t pre_n;
+  int32_t pre_stride;
+  int64_t pre_pos;
+  // ---- this run / this scan round
+  int32_t run_done;     // the chain has stopped for this run (nothing more fits into the chunk, or records are full)
+  int32_t need_chain;   // the per-chain kernel takes the chain from here (a window the strips could not resolve)
+  int32_t scan_job;     // this round: its job, -1 = none
+  int32_t scan_pad;
   float psr_data[kMovingAvgSz];
   float cfo_data[kMovingAvgSz];
-  float avg[2][kConvLen]; // srslte_pss_t::conv_output_avg (lags >= 9726 stay 0), natural lag order
+  float avg[3][kConvLen]; // srslte_pss_t::conv_output_avg (lags >= 9726 stay 0), natural lag order
 };
 
 // ---- wavefront reductions on the VALU cross-lane path (DPP row rotates + 4 readlanes) instead of

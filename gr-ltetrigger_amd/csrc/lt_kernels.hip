@@ -525,7 +525,8 @@ namespace lt {
 
 int call_reach() { return kCallReach; }
 int scan_job_bytes() { return (int)sizeof(ScanJob); }
-int strip_partial_bytes() { return (int)(sizeof(StripPartial) * kStrips); }
+int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips * kScanMaxRound); }
+int scan_max_round() { return kScanMaxRound; }
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
 {
@@ -538,39 +539,39 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
   ScanJob *jobs = reinterpret_cast<ScanJob *>(R.jobs);
   StripPartial *parts = reinterpret_cast<StripPartial *>(R.parts);
   const int64_t t1 = R.t0 + R.n;
-  // ---- plan
-  hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int), stream);
-  if (e != hipSuccess) return e;
+  // ---- rounds of plan, scan, resolve.  An idle chain needs one round per `seg_len` windows; a chain that fires
+  // needs a few more (a round ends for it where it re-aligns, where tracking starts, where it is lost).  Rounds
+  // with nothing left to do cost three empty launches; whatever a chain has not got through after the last one --
+  // and every window the strips cannot resolve -- is the per-chain kernel's.
   {
     PlanArgs p;
     p.state = state; p.jobs = jobs; p.n_jobs = R.n_jobs; p.rec_count = R.rec_count; p.n_channels = R.n_channels;
-    p.rec_cap = R.rec_cap; p.t1 = t1; p.flush = R.flush; p.enable = R.scan && parts ? 1 : 0; p.max_windows = R.parts_windows;
-    p.call_reach = kCallReach;
-    hipLaunchKernelGGL(lt_plan_kernel, dim3((R.n_channels + 63) / 64), dim3(64), 0, stream, p);
-  }
-  // ---- scan + resolve, segment by segment
-  if (R.scan && parts) {
-    // windows a chain at the start of the chunk's reach could search (the plan kernel clips per job)
-    const int64_t span = R.n + R.hist_len;
-    const int max_w = (int)(span / kHalfFrame) + 1 < R.parts_windows ? (int)(span / kHalfFrame) + 1 : R.parts_windows;
+    p.rec_cap = R.rec_cap; p.t1 = t1; p.flush = R.flush; p.enable = R.scan && parts ? 1 : 0;
+    p.track_every = R.track_every; p.call_reach = kCallReach;
     ScanArgs s;
     s.iq = iq; s.ch_stride = R.ch_stride; s.hist = hist; s.hist_stride = R.hist_stride; s.t0 = R.t0; s.n = R.n;
     s.hist_len = R.hist_len; s.jobs = jobs; s.n_jobs = R.n_jobs; s.state = state; s.parts = parts;
-    s.parts_windows = R.parts_windows; s.tab = R.tab; s.prof = nullptr;
+    s.tab = R.tab; s.prof = nullptr;
     ResolveArgs q;
-    q.state = state; q.jobs = jobs; q.parts = parts; q.parts_windows = R.parts_windows; q.recs = R.recs; q.rec_cap = R.rec_cap;
-    q.rec_count = R.rec_count; q.psr_threshold = R.psr_threshold; q.track_every = R.track_every;
-    // up to three jobs per channel (one per root when their alignments differ)
+    q.state = state; q.jobs = jobs; q.parts = parts; q.recs = R.recs; q.rec_cap = R.rec_cap;
+    q.rec_count = R.rec_count; q.t1 = t1; q.flush = R.flush; q.call_reach = kCallReach; q.psr_threshold = R.psr_threshold;
+    q.track_after = R.track_after; q.track_every = R.track_every;
+    const int seg_first = R.seg_first < 1 ? 1 : R.seg_first > kScanMaxRound ? kScanMaxRound : R.seg_first;
+    const int seg_len = R.seg_len < 1 ? 1 : R.seg_len > kScanMaxRound ? kScanMaxRound : R.seg_len;
+    const int64_t windows = (R.n + R.hist_len) / kHalfFrame + 1;
+    int rounds = 1;
+    if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
+    // up to three jobs per channel (one per root when their windows differ)
     const int grid = ((R.n_channels * 3 + 7) / 8) * 8 * kScanWgPerJob;
-    int w = 0, seg = R.seg_first > 0 ? R.seg_first : 1;
-    while (w < max_w) {
-      const int w_end = w + seg < max_w ? w + seg : max_w;
-      s.w_begin = q.w_begin = w;
-      s.w_end = q.w_end = w_end;
+    for (int r = 0; r < rounds; ++r) {
+      hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int), stream);
+      if (e != hipSuccess) return e;
+      p.first_round = r == 0;
+      p.round_windows = r == 0 ? seg_first : seg_len;
+      hipLaunchKernelGGL(lt_plan_kernel, dim3((R.n_channels + 63) / 64), dim3(64), 0, stream, p);
+      if (!p.enable) break;
       hipLaunchKernelGGL(lt_scan_kernel, dim3(grid), dim3(kScanThreads), 0, stream, s);
       hipLaunchKernelGGL(lt_resolve_kernel, dim3(n_chains), dim3(64), 0, stream, q);
-      w = w_end;
-      seg = R.seg_len > 0 ? R.seg_len : max_w;
     }
   }
   if (R.ev_scan_done) (void)hipEventRecord(R.ev_scan_done, stream);
@@ -578,7 +579,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
   {
     ChainArgs c;
     c.iq = iq; c.ch_stride = R.ch_stride; c.hist = hist; c.hist_stride = R.hist_stride; c.t0 = R.t0; c.n = R.n;
-    c.hist_len = R.hist_len; c.flush = R.flush; c.n_channels = R.n_channels; c.state = state; c.jobs = jobs;
+    c.hist_len = R.hist_len; c.flush = R.flush; c.n_channels = R.n_channels; c.state = state;
     c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.tab = R.tab; c.psr_threshold = R.psr_threshold; c.track_after = R.track_after;
     c.track_every = R.track_every;

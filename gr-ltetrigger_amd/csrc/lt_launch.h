@@ -37,10 +37,10 @@ struct RunLaunch {
   int scan = 1;               // 0: every chain goes through the per-chain kernel
   void *jobs = nullptr;       // device, ScanJob[n_channels*3]
   int *n_jobs = nullptr;      // device
-  void *parts = nullptr;      // device, StripPartial[n_channels*3][parts_windows][12]
-  int parts_windows = 0;
-  int seg_first = 2;          // windows in the first scan segment (cells present from the start fire right away)
-  int seg_len = 32;           // windows in the later segments
+  void *parts = nullptr;      // device, scan_parts_bytes_per_chain() per chain
+  int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
+  int seg_len = 32;           // windows per job in the later rounds (<= scan_max_round())
+  int extra_rounds = 3;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr;
@@ -51,7 +51,8 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream);
 hipError_t launch_rebase(void *state, int n_chains, hipStream_t stream);
 int call_reach();
 int scan_job_bytes();
-int strip_partial_bytes(); // per (chain, window)
+int scan_parts_bytes_per_chain();
+int scan_max_round();
 size_t chain_state_bytes();
 size_t chain_state_avg_offset();
 

@@ -2,14 +2,17 @@
 // the exponential average held in registers and nothing but 32-byte partial results per (window, strip)
 // written back.  See lt_scan.h for the strip geometry.
 //
-// A chain is idle when it is neither tracking nor building a score: every general_work call then searches its
-// 9600-sample window, misses and moves on by exactly 9600 samples (lib/pss_impl.cc:163-182, 217), so the
-// windows a chain will search are known in advance as long as it keeps missing.  That is what nearly all
-// chains do nearly all the time, and the search is where the arithmetic is.  The scan runs those windows
-// for all such chains at once, speculatively: lt_resolve_kernel then walks each chain's windows in call order,
-// writes the records of the misses and stops at the first window that fires (PSR over the threshold) or that
-// the strips could not resolve; from that window on the chain belongs to the per-chain kernel (lt_chain.h),
-// which executes general_work call by call.
+// Where a chain will search next is known in advance as long as nothing changes its timing: an idle chain (not
+// tracking, score 0) searches every 9600-sample window, misses and moves on by exactly 9600 samples
+// (lib/pss_impl.cc:163-182, 217); a chain that builds its score or tracks keeps hitting at peak_pos 960 and
+// searches every window, or every (track_every + 1)-th one (lib/pss_impl.cc:163-172, 185-195).  That is what
+// nearly all chains do nearly all the time, and the search is where the arithmetic is.  The work runs in rounds:
+// lt_plan_kernel groups the chains of a channel that will search the same windows into a job, lt_scan_kernel
+// runs the next windows of every job speculatively, and lt_resolve_kernel executes general_work call by call on
+// the results, for as long as the chain stays on the windows that were scanned.  A chain that leaves them -- a
+// first hit re-aligns it, tracking starts or is lost -- joins a new job in the next round; its average is carried
+// over exactly (ChainState: a valid state + the windows to run it through again, or all zeros after
+// srslte_pss_reset).  A window the strips cannot resolve hands the chain to the per-chain kernel (lt_chain_kernel.h).
 //
 // Work decomposition.  A *job* is a capture channel together with the idle chains (roots) of it that share
 // one window alignment -- normally all three.  A job's 12 strips go to four workgroups of three *groups*;
@@ -34,19 +37,26 @@
 
 namespace lt {
 
-// One per (channel, alignment): built by lt_plan_kernel from the chain states.
+// One per (channel, window sequence): built by lt_plan_kernel from the chain states, every round anew.
 struct ScanJob {
-  int64_t pos0;      // absolute position of the job's window 0
+  int64_t pos_a;      // prefix: windows pos_a + k * stride_a * 9600, k < n_a -- lag metric and average only
+  int64_t pos_b;      // the round's windows: pos_b + k * stride_b * 9600, k < n_b
+  int32_t stride_a, n_a, stride_b, n_b;
   int32_t channel;
-  int32_t n_windows; // windows the idle chains may search in this run
-  int32_t roots;     // bit r: chain (channel, N_id_2 = r) is part of the job
-  int32_t rec0[3];   // per root: record index of window 0
+  int32_t roots;      // bit r: chain (channel, N_id_2 = r) is part of the job
+  int32_t zero;       // the job's chains start from an all-zero average
+  int32_t pad;
 };
+__device__ __forceinline__ int64_t job_window_pos(const ScanJob &j, int k)
+{
+  return k < j.n_a ? j.pos_a + (int64_t)k * j.stride_a * kHalfFrame : j.pos_b + (int64_t)(k - j.n_a) * j.stride_b * kHalfFrame;
+}
 
 constexpr int kScanWaves = 12;
 constexpr int kScanThreads = 64 * kScanWaves;
 constexpr int kScanGroups = 3;              // strips per workgroup
 constexpr int kScanWgPerJob = kStrips / kScanGroups;
+constexpr int kScanMaxRound = 64;           // windows per job and round at most (one resolver lane each)
 
 struct ScanArgs {
   const v2f *iq;       // [n_channels][ch_stride]
@@ -57,9 +67,7 @@ struct ScanArgs {
   const ScanJob *jobs;
   const int *n_jobs;
   ChainState *state;   // [n_channels * 3]
-  StripPartial *parts; // [n_channels * 3][parts_windows][12]
-  int64_t parts_windows;
-  int w_begin, w_end;  // this segment: windows [w_begin, w_end) of every job
+  StripPartial *parts; // [n_channels * 3][kScanMaxRound][12]
   const DeviceTables *tab;
   unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
 };
@@ -81,21 +89,14 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   const int quarter = slot % kScanWgPerJob;
   if (job_i >= *a.n_jobs) return;
   const ScanJob job = a.jobs[job_i];
-  const int w_end = a.w_end < job.n_windows ? a.w_end : job.n_windows;
-  if (a.w_begin >= w_end) return;
+  const int n_w = job.n_a + job.n_b;
+  if (n_w <= 0) return;
   // group g = w % 3 owns strip 3 quarter + g; role w / 3: 0 = forward, 1..3 = root 0..2 (the three forward
   // waves land on three different SIMDs)
   const int g = w % kScanGroups, role = w / kScanGroups;
   const int strip = quarter * kScanGroups + g;
   const int root = role - 1;
-  // a root leaves the job for good once the resolver has seen it fire (scan_live cleared)
-  int live_mask = 0;
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-    if ((job.roots >> r) & 1)
-      if (a.state[job.channel * 3 + r].scan_live) live_mask |= 1 << r;
-  if (!live_mask) return;
-  const bool active = role == 0 || ((live_mask >> root) & 1);
+  const bool active = role == 0 || ((job.roots >> root) & 1);
 
   for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw1[i]);
   if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw2[tid]);
@@ -122,16 +123,15 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   // both the vector unit and the LDS busy):
   //   ready[g] = windows whose first two transform stages sit in the forward wave's exchange area (1 at a time)
   //   taken[g] = sum over the root waves of the windows they have read from it
-  const int n_roots = __builtin_popcount(live_mask);
-  const int n_w = w_end - a.w_begin;
+  const int n_roots = __builtin_popcount(job.roots & 7);
 #if LT_SCAN_STAGGER
   for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(LT_SCAN_STAGGER);
 #endif
   if (role == 0) {
     fft::c32 x[16];  // the block being transformed
     fft::c32 xn[16]; // the next window's block, in flight
-    strip_load(cap, job.pos0 + (int64_t)a.w_begin * kHalfFrame, strip, lane, x);
-    if (n_w > 1) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + 1) * kHalfFrame, strip, lane, xn);
+    strip_load(cap, job_window_pos(job, 0), strip, lane, x);
+    if (n_w > 1) strip_load(cap, job_window_pos(job, 1), strip, lane, xn);
     for (int k = 0; k < n_w; ++k) {
       int ln = lane; // (opaque per iteration: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
       asm volatile("" : "+v"(ln));
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
       if (lane == 0) __hip_atomic_store(&sync_ready[g], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int R = 0; R < 16; ++R) x[R] = xn[R];
-      if (k + 2 < n_w) strip_load(cap, job.pos0 + (int64_t)(a.w_begin + k + 2) * kHalfFrame, strip, ln, xn);
+      if (k + 2 < n_w) strip_load(cap, job_window_pos(job, k + 2), strip, ln, xn);
     }
   } else if (active) {
 #ifdef LT_ROOT_PRIO
@@ -151,9 +151,16 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #endif
     fft::c32 x[16]; // spectrum, then lags
     float ema[kStripRegs];
-    ChainState *st = a.state + job.channel * 3 + root;
-    strip_ema_load(st->avg[st->ema_sel], strip, lane, ema);
-    StripPartial *parts = a.parts + ((int64_t)(job.channel * 3 + root) * a.parts_windows + a.w_begin) * kStrips + strip;
+    const int chain = job.channel * 3 + root;
+    ChainState *st = a.state + chain;
+    const int sel = st->ema_sel;
+    if (job.zero) {
+#pragma unroll
+      for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+    } else {
+      strip_ema_load(st->avg[sel], strip, lane, ema);
+    }
+    StripPartial *parts = a.parts + (int64_t)chain * kScanMaxRound * kStrips + strip;
 #ifdef LT_SCAN_PROF
     unsigned long long pr[8] = {0}, tp = __builtin_amdgcn_s_memtime();
 #define LT_PSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; }
@@ -175,38 +182,47 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #else
       strip_root_update(strip, ln, x, SPEC[root], TW1, TW2, e, ema);
 #endif
-      StripPartial p;
+      if (k < job.n_a) {
+        // prefix window: the chain has been through it already (its record exists); after the last one the
+        // average is a state the chain can be restarted from
+        if (k == job.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
+      } else {
+        StripPartial p;
 #ifndef LT_ABL_NO_RESOLVE
-      strip_resolve(ema, strip, ln, p);
+        strip_resolve(ema, strip, ln, p);
 #else
-      p.m1 = ema[3]; p.p1 = 0; p.s = ema[5]; p.lb = p.ub = 0; p.a0 = 0.f; p.flags = 0; p.pad = 0;
+        p.m1 = ema[3]; p.p1 = 0; p.s = ema[5]; p.lb = p.ub = 0; p.a0 = 0.f; p.flags = 0; p.pad = 0;
 #endif
-      if (lane == 0) parts[(int64_t)k * kStrips] = p;
+        if (lane == 0) parts[(int64_t)(k - job.n_a) * kStrips] = p;
+      }
       LT_PSTAMP(7) // resolve + store
     }
 #ifdef LT_SCAN_PROF
     if (a.prof && blockIdx.x == 8 && w == 7 && lane == 0)
       for (int i = 0; i < 8; ++i) a.prof[i] = pr[i];
 #endif
-    strip_ema_store(st->avg[st->ema_sel ^ 1], strip, lane, ema);
+    strip_ema_store(st->avg[(sel + 2) % 3], strip, lane, ema);
   }
 }
 
-// ---------------------------------------------------------------- plan: which chains does the scan serve?
-// One thread per channel.  A chain is eligible when it is idle (not tracking, score 0, no tracking_lost pending:
-// every call searches, and a miss moves on by exactly 9600 samples, lib/pss_impl.cc:163-182,217) and at
-// least one window fits into the chunk.  Chains of a channel at the same stream position share a job.
+// ---------------------------------------------------------------- plan: the jobs of the next round
+// One thread per channel.  A chain can be served when its next search is at a position that is known now
+// (always: the calls between two searches of a tracked chain neither search nor move it off its timing,
+// lib/pss_impl.cc:170-172,185-186) and that search may start in this chunk.  Chains of a channel that will search the
+// same windows from a plainly stored average share a job (one forward transform per window for all of them).
 struct PlanArgs {
   ChainState *state;
   ScanJob *jobs;
   int *n_jobs;       // zeroed before the launch
-  int *rec_count;    // [n_channels*3]: zeroed here
+  int *rec_count;    // [n_channels*3]: zeroed in the first round
   int n_channels;
   int rec_cap;
   int64_t t1;        // absolute end of the chunk
   int flush;
   int enable;        // 0: no chain goes to the scan (lt_batch_set_mode 0)
-  int max_windows;   // room in the partial-result array
+  int round_windows; // windows per job in this round
+  int first_round;
+  int track_every;
   int call_reach;    // kCallReach (lt_chain_kernel.h)
 };
 
@@ -214,64 +230,75 @@ __global__ void lt_plan_kernel(PlanArgs a)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.n_channels) return;
-  int nwin[3];
-  int64_t pos[3];
+  int n[3], stride[3];
+  int64_t first[3];
+  bool plain[3]; // the average is avg[ema_sel] as it stands
+  const int64_t limit = a.t1 - (a.flush ? kHalfFrame : a.call_reach); // last position a call may start at
   for (int r = 0; r < 3; ++r) {
     ChainState *st = a.state + c * 3 + r;
-    a.rec_count[c * 3 + r] = 0;
-    st->scan_job = -1;
-    st->scan_live = 0;
-    st->scan_done = 0;
-    st->scan_seg0 = 0;
-    pos[r] = st->pos;
-    const bool idle = !st->is_tracking && st->score == 0 && !st->tracking_lost;
-    int64_t n = 0;
-    if (idle && a.enable) {
-      // calls that may start in this chunk (the per-chain kernel applies the same rule)
-      const int64_t room = a.t1 - pos[r] - (a.flush ? kHalfFrame : a.call_reach);
-      n = room >= 0 ? room / kHalfFrame + 1 : 0;
-      if (n > a.rec_cap) n = a.rec_cap;
-      if (n > a.max_windows) n = a.max_windows;
+    if (a.first_round) {
+      a.rec_count[c * 3 + r] = 0;
+      st->run_done = 0;
+      st->need_chain = 0;
     }
-    nwin[r] = (int)n;
+    st->scan_job = -1;
+    n[r] = 0;
+    stride[r] = st->is_tracking ? a.track_every + 1 : 1;
+    // the calls before the next search emit without searching: timer of them (lib/pss_impl.cc:170-172)
+    first[r] = st->pos + (st->is_tracking ? (int64_t)st->timer * kHalfFrame : 0);
+    plain[r] = st->pre_n == 0 && !st->ema_zero;
+    if (!a.enable || st->run_done || st->need_chain || st->tracking_lost) continue;
+    if (first[r] > limit) continue;
+    int64_t m = (limit - first[r]) / ((int64_t)stride[r] * kHalfFrame) + 1;
+    const int64_t room = (a.rec_cap - a.rec_count[c * 3 + r]) / stride[r]; // a window makes at most `stride` records
+    if (m > room) m = room;
+    if (m > a.round_windows) m = a.round_windows;
+    if (m > kScanMaxRound - st->pre_n) m = kScanMaxRound - st->pre_n;
+    n[r] = m > 0 ? (int)m : 0;
   }
   for (int r = 0; r < 3; ++r) {
-    if (nwin[r] <= 0) continue;
+    if (n[r] <= 0) continue;
     bool leader = true;
-    for (int q = 0; q < r; ++q) leader = leader && !(nwin[q] > 0 && pos[q] == pos[r]);
+    for (int q = 0; q < r; ++q) leader = leader && !(n[q] > 0 && plain[q] && plain[r] && first[q] == first[r] && stride[q] == stride[r]);
     if (!leader) continue;
     const int j = atomicAdd(a.n_jobs, 1);
+    const ChainState *st = a.state + c * 3 + r;
     ScanJob job;
-    job.pos0 = pos[r];
+    job.pos_a = st->pre_pos; job.stride_a = st->pre_stride; job.n_a = st->pre_n;
+    job.pos_b = first[r]; job.stride_b = stride[r]; job.n_b = n[r];
     job.channel = c;
-    job.n_windows = nwin[r];
     job.roots = 0;
+    job.zero = st->ema_zero;
+    job.pad = 0;
     for (int q = r; q < 3; ++q)
-      if (nwin[q] > 0 && pos[q] == pos[r]) {
+      if (q == r || (n[q] > 0 && plain[q] && plain[r] && first[q] == first[r] && stride[q] == stride[r])) {
         job.roots |= 1 << q;
+        if (n[q] < job.n_b) job.n_b = n[q];
         a.state[c * 3 + q].scan_job = j;
-        a.state[c * 3 + q].scan_live = 1;
       }
-    job.rec0[0] = job.rec0[1] = job.rec0[2] = 0;
     a.jobs[j] = job;
   }
 }
 
-// ---------------------------------------------------------------- resolve: partials -> records, in call order
-// One wave per chain, one lane per window (64 at a time): every lane combines the 12 partials of its window
-// (resolve_window); the first window that fires -- PSR over the threshold -- or that the strips could not
-// resolve ends the chain's time in the scan.  The windows before it are misses: general_work searched, did
-// not emit and consumed 9600 samples (lib/pss_impl.cc:163-182, 217); their records are written here.
+// ---------------------------------------------------------------- resolve: general_work on the scanned windows
+// One wave per chain.  Lane k combines the 12 partials of the job's window k (resolve_window); then the calls run
+// in order, wave-uniform: the search result of window k goes through lib/pss_impl.cc:163-223 exactly as the
+// per-chain kernel does it (score, tracking, alignment, one record per call), followed by the calls that do not
+// search.  The chain stays in the job as long as its next search is the job's next window and its average is
+// the one the scan carried on; it leaves it when a hit re-aligns it, when tracking starts or is lost
+// (srslte_pss_reset: the average restarts from zero) or when nothing more fits into the chunk.
 struct ResolveArgs {
   ChainState *state;
   const ScanJob *jobs;
   const StripPartial *parts;
-  int64_t parts_windows;
   lt_record *recs;
   int rec_cap;
   int *rec_count;
-  int w_begin, w_end; // the scan segment just run
+  int64_t t1;
+  int flush;
+  int call_reach;
   float psr_threshold;
+  int track_after;
   int track_every;
 };
 
@@ -279,80 +306,147 @@ __global__ __launch_bounds__(64) void lt_resolve_kernel(ResolveArgs a)
 {
   const int chain = blockIdx.x, lane = threadIdx.x;
   ChainState *st = a.state + chain;
-  if (!st->scan_live) return;
+  if (st->scan_job < 0) return;
   const ScanJob job = a.jobs[st->scan_job];
-  const int w_end = a.w_end < job.n_windows ? a.w_end : job.n_windows;
-  if (a.w_begin >= w_end) return;
-  const StripPartial *parts = a.parts + (int64_t)chain * a.parts_windows * kStrips;
+  const int channel = chain / 3, n_id_2 = chain % 3;
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
-  float psr_max = st->psr_max, last_psr = st->psr;
-  int last_peak = st->peak_pos;
+  // every window's search result, one per lane
+  WindowResult wr;
+  wr.peak_pos = 0; wr.peak_value = 0.f; wr.psr = 0.f; wr.exact = true;
+  if (lane < job.n_b) wr = resolve_window(a.parts + ((int64_t)chain * kScanMaxRound + lane) * kStrips);
+
+  int64_t pos = st->pos;
+  int is_tracking = st->is_tracking, score = st->score, timer = st->timer, tracking_lost = st->tracking_lost;
+  int peak_pos = st->peak_pos;
   uint32_t psr_i = st->psr_i;
-  const float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
-  const int call_base = st->n_calls - a.w_begin; // window k of the job is call call_base + k (records start at 0 each run)
-  int fired_at = -1;
-  for (int base = a.w_begin; base < w_end; base += 64) {
-    const int k = base + lane;
-    const bool valid = k < w_end;
-    WindowResult r;
-    r.peak_pos = 0; r.peak_value = 0.f; r.psr = 0.f; r.exact = true;
-    if (valid) r = resolve_window(parts + (int64_t)k * kStrips);
-    const bool fire = valid && (!r.exact || r.psr > a.psr_threshold);
-    const unsigned long long fm = __ballot(fire);
-    const int first = fm ? __builtin_ctzll(fm) : 64;
-    const bool miss = valid && lane < first;
-    // d_psr_max over the calls so far (if (psr > psr_max) psr_max = psr), as an inclusive prefix maximum
-    float pm = miss ? r.psr : -FLT_MAX;
-    if (!(pm == pm)) pm = -FLT_MAX; // a NaN never raises the maximum
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const float o = __shfl_up(pm, d);
-      if (lane >= d) pm = fmaxf(pm, o);
+  float psr = st->psr, psr_max = st->psr_max;
+  int nrec = a.rec_count[chain];
+  const int call_base = st->n_calls - nrec;
+  int n_emits = 0;
+  const int64_t limit = a.t1 - (a.flush ? kHalfFrame : a.call_reach);
+  auto put = [&](int64_t in_pos, int64_t out_pos, uint32_t flags, int used_peak, float pv) {
+    if (lane == 0) {
+      lt_record r;
+      r.in_pos = in_pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
+      r.call_idx = call_base + nrec; r.flags = flags; r.peak_pos = used_peak; r.score = score;
+      r.psr = psr; r.peak_value = pv; r.cfo = 0.f; r.mean_cfo = 0.f;
+      r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+      r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+      r.psr_max = psr_max; r.timer = timer;
+      recs[nrec] = r;
     }
-    const float my_max = fmaxf(psr_max, pm);
-    if (miss) {
-      lt_record rec;
-      rec.in_pos = job.pos0 + (int64_t)k * kHalfFrame; rec.out_pos = -1; rec.channel = chain / 3; rec.n_id_2 = chain % 3;
-      rec.call_idx = call_base + k; rec.flags = LT_F_SEARCHED; rec.peak_pos = r.peak_pos; rec.score = 0;
-      rec.psr = r.psr; rec.peak_value = r.peak_value; rec.cfo = 0.f; rec.mean_cfo = 0.f;
-      rec.m_norm_avg = m_norm_avg; rec.m_ext_avg = m_ext_avg; rec.m0_value = 0.f;
-      rec.m1_value = 0.f; rec.m0 = -1; rec.m1 = -1; rec.n_id_1 = -1; rec.cell_id = -1;
-      rec.psr_max = my_max; rec.timer = a.track_every;
-      recs[k] = rec;
-      st->psr_data[(psr_i + (uint32_t)(k - base)) % kMovingAvgSz] = r.psr; // d_psr_data ring (lib/pss_impl.cc:166)
+    nrec++;
+  };
+  // the calls of a tracked chain between two searches (lib/pss_impl.cc:170-172, 184-204 with frame_start = 0)
+  auto run_timer_calls = [&]() {
+    while (is_tracking && timer > 0 && pos <= limit && nrec < a.rec_cap) {
+      timer--;
+      put(pos, pos, LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING, kSlotLen, 0.f);
+      n_emits++;
+      pos += kHalfFrame;
     }
-    const int n_miss = first < 64 ? first : (w_end - base < 64 ? w_end - base : 64);
-    if (n_miss > 0) {
-      psr_max = __shfl(my_max, n_miss - 1);
-      last_psr = __shfl(r.psr, n_miss - 1);
-      last_peak = __shfl(r.peak_pos, n_miss - 1);
-      psr_i += (uint32_t)n_miss;
-    }
-    if (first < 64) {
-      fired_at = base + first;
+  };
+
+  int used = 0;          // windows of the job whose search has been executed
+  bool ema_reset = false, stop_run = false, need_chain = false;
+  run_timer_calls();
+  for (int k = 0; k < job.n_b; ++k) {
+    const int64_t pk = job.pos_b + (int64_t)k * job.stride_b * kHalfFrame;
+    if (ema_reset || pos != pk || (is_tracking ? a.track_every + 1 : 1) != job.stride_b) break; // off the job's windows
+    if (is_tracking && timer != 0) break; // (the calls before the search did not all fit)
+    if (!(pos <= limit && nrec < a.rec_cap)) {
+      stop_run = true;
       break;
     }
+    if (!__shfl((int)wr.exact, k)) { // a lobe the strips could not close: the per-chain kernel searches this window
+      need_chain = true;
+      break;
+    }
+    used = k + 1;
+    // ---- lib/pss_impl.cc:163-172: the search
+    uint32_t flags = LT_F_SEARCHED;
+    timer = a.track_every;
+    peak_pos = __shfl(wr.peak_pos, k);
+    psr = __shfl(wr.psr, k);
+    const float peak_value = __shfl(wr.peak_value, k);
+    if (lane == 0) st->psr_data[psr_i % kMovingAvgSz] = psr;
+    psr_i++;
+    const int used_peak_pos = peak_pos;
+    // ---- score, lib/pss_impl.cc:174-182 (incr_score :111-127, reset_score :129-152)
+    const bool over = psr > a.psr_threshold;
+    if (over) {
+      if (!(is_tracking && score == a.track_after)) {
+        score++;
+        if (!is_tracking && score == a.track_after) {
+          is_tracking = 1;
+          ema_reset = true; // srslte_pss_reset
+        }
+      }
+      flags |= LT_F_OVER;
+    } else if (score != 0) {
+      score = 0;
+      timer = 0;
+      is_tracking = 0;
+      ema_reset = true;
+      psr_i = 0;
+      tracking_lost = 1;
+    }
+    if (psr > psr_max) psr_max = psr;
+    int64_t out_pos = -1, next_pos;
+    if (over || tracking_lost) { // ---- lib/pss_impl.cc:184-214
+      const int frame_start = peak_pos - kSlotLen;
+      peak_pos = kSlotLen;
+      const int64_t hf0 = pos + frame_start;
+      if (hf0 + kHalfFrame > a.t1) { // (flush only) quirk q1 normalised: never read past the capture
+        stop_run = true;
+        break;
+      }
+      next_pos = hf0 + kHalfFrame;
+      out_pos = hf0;
+      flags |= LT_F_EMITTED;
+      if (is_tracking) {
+        flags |= LT_F_SSS_RAN;
+      } else {
+        flags |= LT_F_TAG_LOST;
+        tracking_lost = 0;
+      }
+      n_emits++;
+    } else {
+      next_pos = pos + kHalfFrame; // lib/pss_impl.cc:217
+    }
+    if (is_tracking) flags |= LT_F_TRACKING;
+    put(pos, out_pos, flags, used_peak_pos, peak_value);
+    pos = next_pos;
+    run_timer_calls();
   }
   if (lane == 0) {
-    const int done = fired_at >= 0 ? fired_at : w_end; // windows of the job turned into records so far
-    const int n_new = done - a.w_begin;
-    st->pos = job.pos0 + (int64_t)done * kHalfFrame;
-    st->n_calls += n_new;
+    st->pos = pos;
+    st->is_tracking = is_tracking; st->score = score; st->timer = timer;
+    st->tracking_lost = tracking_lost; st->peak_pos = peak_pos;
     st->psr_i = psr_i;
-    st->psr_max = psr_max;
-    if (n_new > 0) {
-      st->psr = last_psr;
-      st->peak_pos = last_peak;
-      st->timer = a.track_every;
-    }
-    st->scan_done = done;
-    a.rec_count[chain] = done;
-    if (fired_at >= 0) {
-      st->scan_live = 0;          // the per-chain kernel takes over at window `fired_at` ...
-      st->scan_seg0 = a.w_begin;  // ... from the average as it was before this segment (avg[ema_sel])
-    } else {
-      st->ema_sel ^= 1;           // the scan has left the average after window w_end - 1 in the other buffer
-    }
+    st->n_calls = call_base + nrec; st->n_emits += n_emits;
+    st->psr = psr; st->psr_max = psr_max;
+    a.rec_count[chain] = nrec;
+    if (stop_run) st->run_done = 1;
+    if (need_chain) st->need_chain = 1;
+    // ---- where the average stands now
+    const int sel = st->ema_sel;
+    if (ema_reset) { // zeros, whatever the scan went on to compute
+      st->ema_zero = 1;
+      st->pre_n = 0;
+    } else if (used == job.n_b) { // all of the round's windows: the scan's final state is the chain's
+      st->ema_sel = (sel + 2) % 3;
+      st->ema_zero = 0;
+      st->pre_n = 0;
+    } else if (used > 0) { // the first `used` windows only: from the state behind the prefix, run through them again
+      if (job.n_a > 0) {
+        st->ema_sel = (sel + 1) % 3;
+        st->ema_zero = 0;
+      }
+      st->pre_pos = job.pos_b;
+      st->pre_stride = job.stride_b;
+      st->pre_n = used;
+    } // (used == 0: nothing consumed, the chain's average is described as before)
   }
 }
 

@@ -1,5 +1,5 @@
-// Stand-alone timing of lt_scan_kernel (csrc/lt_scan_kernels.h) on random data: 64 jobs x 200 windows, all
-// three roots live.  Also checks the DPP whole-wave rotates the strip resolver relies on.
+// Stand-alone timing of lt_scan_kernel (csrc/lt_scan_kernels.h) on random data: 64 jobs x 64 windows (one scan round),
+// all three roots live.  Also checks the DPP whole-wave rotates the strip resolver relies on.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o build/scan_bench tools/scan_bench.hip csrc/lt_tables.cpp
 #include "../gr-ltetrigger_amd/csrc/lt_scan_kernels.h"
 
@@ -22,7 +22,8 @@ __global__ void k_rot(float *out)
 int main(int argc, char **argv)
 {
   const int n_ch = argc > 1 ? atoi(argv[1]) : 64;
-  const int n_win = argc > 2 ? atoi(argv[2]) : 200;
+  int n_win = argc > 2 ? atoi(argv[2]) : kScanMaxRound;
+  if (n_win > kScanMaxRound) n_win = kScanMaxRound;
   const int64_t n = (int64_t)n_win * kHalfFrame;
   {
     float *d;
@@ -50,11 +51,12 @@ int main(int argc, char **argv)
   CK(hipMemcpy(diq, hiq.data(), hiq.size() * sizeof(float), hipMemcpyHostToDevice));
   std::vector<ScanJob> jobs(n_ch);
   for (int c = 0; c < n_ch; ++c) {
-    jobs[c].pos0 = 0;
+    jobs[c].pos_a = 0; jobs[c].stride_a = 1; jobs[c].n_a = 0;
+    jobs[c].pos_b = 0; jobs[c].stride_b = 1; jobs[c].n_b = n_win;
     jobs[c].channel = c;
-    jobs[c].n_windows = n_win;
     jobs[c].roots = 7;
-    jobs[c].rec0[0] = jobs[c].rec0[1] = jobs[c].rec0[2] = 0;
+    jobs[c].zero = 1;
+    jobs[c].pad = 0;
   }
   ScanJob *djobs;
   int *dnj;
@@ -68,15 +70,13 @@ int main(int argc, char **argv)
   {
     std::vector<ChainState> hst(n_ch * 3);
     memset(hst.data(), 0, sizeof(ChainState) * hst.size());
-    for (auto &c : hst) c.scan_live = 1;
     CK(hipMemcpy(dst, hst.data(), sizeof(ChainState) * hst.size(), hipMemcpyHostToDevice));
   }
   StripPartial *dparts;
-  CK(hipMalloc(&dparts, sizeof(StripPartial) * (size_t)n_ch * 3 * n_win * kStrips));
+  CK(hipMalloc(&dparts, sizeof(StripPartial) * (size_t)n_ch * 3 * kScanMaxRound * kStrips));
   ScanArgs a;
   a.iq = diq; a.ch_stride = n; a.hist = nullptr; a.hist_stride = 0; a.t0 = 0; a.n = n; a.hist_len = 0;
-  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.parts_windows = n_win;
-  a.w_begin = 0; a.w_end = n_win; a.tab = dtab;
+  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.tab = dtab;
   unsigned long long *dprof;
   CK(hipMalloc(&dprof, 64));
   CK(hipMemset(dprof, 0, 64));
