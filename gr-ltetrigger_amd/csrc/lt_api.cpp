@@ -157,7 +157,7 @@ struct lt_batch {
   int64_t hist_cap = 0;
   int64_t t0 = 0;            // absolute stream position of the next chunk
   int mode = 1;              // 0 per-chain kernel only, 1 grid scan + per-chain kernel
-  int seg_first = 2, seg_len = 32;
+  int seg_first = 2, seg_len = 64;
   bool pending_reset = false; // lt_batch_reset: applied on the stream of the next run, in front of it
   // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, scan done, per-chain kernel done, end
   static constexpr int kPhaseRing = 8;
@@ -523,8 +523,8 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_state, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_recs, sizeof(lt_record) * nchains * (size_t)b->rec_cap);
   if (e == hipSuccess) e = hipMalloc(&b->d_count, sizeof(int) * nchains);
-  if (e == hipSuccess) e = hipMalloc(&b->d_jobs, (size_t)lt::scan_job_bytes() * nchains);
-  if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&b->d_jobs, (size_t)lt::scan_job_bytes() * nchains * 2);
+  if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int) * 2 * (size_t)(lt::scan_max_rounds() + 1));
   if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::scan_parts_bytes_per_chain() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)16 * nchains * (size_t)b->rec_cap);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);

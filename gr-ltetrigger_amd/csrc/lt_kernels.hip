@@ -521,12 +521,19 @@ __global__ __launch_bounds__(256) void lt_hist_kernel(HistArgs a)
 // Host-callable launchers (the C-ABI in lt_api.cpp only sees these).
 #include "lt_launch.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 namespace lt {
+
+constexpr int kMaxRounds = 256; // scan rounds per run at most (the per-chain kernel takes what is left)
 
 int call_reach() { return kCallReach; }
 int scan_job_bytes() { return (int)sizeof(ScanJob); }
 int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips * kScanMaxRound); }
 int scan_max_round() { return kScanMaxRound; }
+int scan_max_rounds() { return kMaxRounds; }
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
 {
@@ -544,16 +551,19 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
   // with nothing left to do cost three empty launches; whatever a chain has not got through after the last one --
   // and every window the strips cannot resolve -- is the per-chain kernel's.
   {
+    // jobs and their counters alternate between two buffers: a round's resolve launch reads this round's jobs
+    // and writes the next round's
+    ScanJob *jobs2[2] = {jobs, jobs + n_chains};
     PlanArgs p;
-    p.state = state; p.jobs = jobs; p.n_jobs = R.n_jobs; p.rec_count = R.rec_count; p.n_channels = R.n_channels;
+    p.state = state; p.rec_count = R.rec_count; p.n_channels = R.n_channels;
     p.rec_cap = R.rec_cap; p.t1 = t1; p.flush = R.flush; p.enable = R.scan && parts ? 1 : 0;
-    p.track_every = R.track_every; p.call_reach = kCallReach;
+    p.track_after = R.track_after; p.track_every = R.track_every; p.call_reach = kCallReach;
     ScanArgs s;
     s.iq = iq; s.ch_stride = R.ch_stride; s.hist = hist; s.hist_stride = R.hist_stride; s.t0 = R.t0; s.n = R.n;
-    s.hist_len = R.hist_len; s.jobs = jobs; s.n_jobs = R.n_jobs; s.state = state; s.parts = parts;
+    s.hist_len = R.hist_len; s.state = state; s.parts = parts;
     s.tab = R.tab; s.prof = nullptr;
     ResolveArgs q;
-    q.state = state; q.jobs = jobs; q.parts = parts; q.recs = R.recs; q.rec_cap = R.rec_cap;
+    q.state = state; q.parts = parts; q.recs = R.recs; q.rec_cap = R.rec_cap;
     q.rec_count = R.rec_count; q.t1 = t1; q.flush = R.flush; q.call_reach = kCallReach; q.psr_threshold = R.psr_threshold;
     q.track_after = R.track_after; q.track_every = R.track_every;
     const int seg_first = R.seg_first < 1 ? 1 : R.seg_first > kScanMaxRound ? kScanMaxRound : R.seg_first;
@@ -561,17 +571,49 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     const int64_t windows = (R.n + R.hist_len) / kHalfFrame + 1;
     int rounds = 1;
     if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
+    if (rounds > kMaxRounds) rounds = kMaxRounds;
+    hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int) * 2 * (kMaxRounds + 1), stream);
+    if (e != hipSuccess) return e;
     // up to three jobs per channel (one per root when their windows differ)
-    const int grid = ((R.n_channels * 3 + 7) / 8) * 8 * kScanWgPerJob;
-    for (int r = 0; r < rounds; ++r) {
-      hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int), stream);
-      if (e != hipSuccess) return e;
-      p.first_round = r == 0;
-      p.round_windows = r == 0 ? seg_first : seg_len;
-      hipLaunchKernelGGL(lt_plan_kernel, dim3((R.n_channels + 63) / 64), dim3(64), 0, stream, p);
-      if (!p.enable) break;
+    const int grid = (((R.n_channels * 3 + 7) / 8) * 8 + 8) * kScanWgPerJob;
+    p.first_round = 1;
+    p.round_windows = seg_first;
+    p.jobs = jobs2[0];
+    p.n_jobs = R.n_jobs;
+    p.jobs_cap = s.jobs_cap = n_chains;
+    hipLaunchKernelGGL(lt_plan_kernel, dim3((R.n_channels + 63) / 64), dim3(64), 0, stream, p);
+    for (int r = 0; r < rounds && p.enable; ++r) {
+      s.jobs = q.jobs = jobs2[r & 1];
+      s.n_jobs = R.n_jobs + 2 * r;
+      q.plan_next = r + 1 < rounds;
+      q.next = p;
+      q.next.first_round = 0;
+      q.next.round_windows = seg_len;
+      q.next.jobs = jobs2[(r + 1) & 1];
+      q.next.n_jobs = R.n_jobs + 2 * (r + 1);
       hipLaunchKernelGGL(lt_scan_kernel, dim3(grid), dim3(kScanThreads), 0, stream, s);
-      hipLaunchKernelGGL(lt_resolve_kernel, dim3(n_chains), dim3(64), 0, stream, q);
+      hipLaunchKernelGGL(lt_resolve_kernel, dim3(R.n_channels), dim3(192), 0, stream, q);
+      if (getenv("LT_DEBUG_JOBS")) { // diagnostics: the jobs of this round
+        (void)hipStreamSynchronize(stream);
+        int njj[2] = {0, 0};
+        (void)hipMemcpy(njj, R.n_jobs + 2 * r, sizeof(njj), hipMemcpyDeviceToHost);
+        std::vector<ScanJob> all((size_t)n_chains), hj;
+        (void)hipMemcpy(all.data(), jobs2[r & 1], sizeof(ScanJob) * (size_t)n_chains, hipMemcpyDeviceToHost);
+        for (int i = 0; i < njj[0]; ++i) hj.push_back(all[(size_t)i]);
+        for (int i = 0; i < njj[1]; ++i) hj.push_back(all[(size_t)(n_chains - 1 - i)]);
+        const int nj = njj[0] + njj[1];
+        int hist[4][4] = {};
+        long wsum[4] = {};
+        for (const ScanJob &j : hj) {
+          const int nr = __builtin_popcount(j.roots & 7);
+          hist[nr][j.stride_b > 1 ? 2 : (j.n_a > 0 ? 1 : 0)]++;
+          wsum[nr] += j.n_a + j.n_b;
+        }
+        fprintf(stderr, "round %d: %d jobs;", r, nj);
+        for (int nr = 1; nr <= 3; ++nr)
+          fprintf(stderr, "  %d-root: %d plain, %d with prefix, %d strided, %ld windows;", nr, hist[nr][0], hist[nr][1], hist[nr][2], wsum[nr]);
+        fprintf(stderr, "\n");
+      }
     }
   }
   if (R.ev_scan_done) (void)hipEventRecord(R.ev_scan_done, stream);

@@ -35,12 +35,12 @@ struct RunLaunch {
   int track_after = 16;
   int track_every = 8;
   int scan = 1;               // 0: every chain goes through the per-chain kernel
-  void *jobs = nullptr;       // device, ScanJob[n_channels*3]
-  int *n_jobs = nullptr;      // device
+  void *jobs = nullptr;       // device, 2 x ScanJob[n_channels*3]
+  int *n_jobs = nullptr;      // device, 2 x (scan_max_rounds() + 1) counters
   void *parts = nullptr;      // device, scan_parts_bytes_per_chain() per chain
   int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
-  int seg_len = 32;           // windows per job in the later rounds (<= scan_max_round())
-  int extra_rounds = 3;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
+  int seg_len = 64;           // windows per job in the later rounds (<= scan_max_round())
+  int extra_rounds = 2;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr;
@@ -53,6 +53,7 @@ int call_reach();
 int scan_job_bytes();
 int scan_parts_bytes_per_chain();
 int scan_max_round();
+int scan_max_rounds();
 size_t chain_state_bytes();
 size_t chain_state_avg_offset();
 

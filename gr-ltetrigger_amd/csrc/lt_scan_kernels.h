@@ -64,8 +64,9 @@ struct ScanArgs {
   const v2f *hist;     // [n_channels][hist_stride] or null
   int64_t hist_stride;
   int64_t t0, n, hist_len;
-  const ScanJob *jobs;
-  const int *n_jobs;
+  const ScanJob *jobs; // [jobs_cap]: long jobs from the front, short ones from the back
+  const int *n_jobs;   // [2]: how many of each
+  int jobs_cap;
   ChainState *state;   // [n_channels * 3]
   StripPartial *parts; // [n_channels * 3][kScanMaxRound][12]
   const DeviceTables *tab;
@@ -85,9 +86,16 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   // by 213 samples, so the second read of those comes from that XCD's L2
   const int b = blockIdx.x;
   const int slot = b >> 3;
-  const int job_i = (slot / kScanWgPerJob) * 8 + (b & 7);
   const int quarter = slot % kScanWgPerJob;
-  if (job_i >= *a.n_jobs) return;
+  // long jobs first (they sit at the front of the job array, the short ones at its back): the workgroups of a launch
+  // start in index order, and a long job that starts late ends late
+  int job_i = (slot / kScanWgPerJob) * 8 + (b & 7);
+  const int n_front = a.n_jobs[0], n_back = a.n_jobs[1];
+  if (job_i >= n_front) {
+    job_i -= (n_front + 7) / 8 * 8; // (the back jobs start on a fresh group of 8 workgroups: XCD pairing as above)
+    if (job_i < 0 || job_i >= n_back) return;
+    job_i = a.jobs_cap - 1 - job_i;
+  }
   const ScanJob job = a.jobs[job_i];
   const int n_w = job.n_a + job.n_b;
   if (n_w <= 0) return;
@@ -128,10 +136,12 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(LT_SCAN_STAGGER);
 #endif
   if (role == 0) {
-    fft::c32 x[16];  // the block being transformed
-    fft::c32 xn[16]; // the next window's block, in flight
+    fft::c32 x[16];   // the block being transformed
+    fft::c32 xn[16];  // the next two windows' blocks, in flight: a job with one live root, or one whose windows lie
+    fft::c32 xn2[16]; // 9 half-frames apart, turns a window over faster than one memory latency
     strip_load(cap, job_window_pos(job, 0), strip, lane, x);
     if (n_w > 1) strip_load(cap, job_window_pos(job, 1), strip, lane, xn);
+    if (n_w > 2) strip_load(cap, job_window_pos(job, 2), strip, lane, xn2);
     for (int k = 0; k < n_w; ++k) {
       int ln = lane; // (opaque per iteration: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
       asm volatile("" : "+v"(ln));
@@ -142,8 +152,11 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
       LT_LDS_ORDER;
       if (lane == 0) __hip_atomic_store(&sync_ready[g], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-      for (int R = 0; R < 16; ++R) x[R] = xn[R];
-      if (k + 2 < n_w) strip_load(cap, job_window_pos(job, k + 2), strip, ln, xn);
+      for (int R = 0; R < 16; ++R) {
+        x[R] = xn[R];
+        xn[R] = xn2[R];
+      }
+      if (k + 3 < n_w) strip_load(cap, job_window_pos(job, k + 3), strip, ln, xn2);
     }
   } else if (active) {
 #ifdef LT_ROOT_PRIO
@@ -212,8 +225,9 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 // same windows from a plainly stored average share a job (one forward transform per window for all of them).
 struct PlanArgs {
   ChainState *state;
-  ScanJob *jobs;
-  int *n_jobs;       // zeroed before the launch
+  ScanJob *jobs;     // [jobs_cap]
+  int *n_jobs;       // [2]: jobs allocated from the front (long) / from the back (short); zeroed before the launch
+  int jobs_cap;
   int *rec_count;    // [n_channels*3]: zeroed in the first round
   int n_channels;
   int rec_cap;
@@ -222,14 +236,14 @@ struct PlanArgs {
   int enable;        // 0: no chain goes to the scan (lt_batch_set_mode 0)
   int round_windows; // windows per job in this round
   int first_round;
+  int track_after;
   int track_every;
   int call_reach;    // kCallReach (lt_chain_kernel.h)
 };
 
-__global__ void lt_plan_kernel(PlanArgs a)
+// the jobs of channel c for the next round
+__device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.n_channels) return;
   int n[3], stride[3];
   int64_t first[3];
   bool plain[3]; // the average is avg[ema_sel] as it stands
@@ -253,6 +267,15 @@ __global__ void lt_plan_kernel(PlanArgs a)
     const int64_t room = (a.rec_cap - a.rec_count[c * 3 + r]) / stride[r]; // a window makes at most `stride` records
     if (m > room) m = room;
     if (m > a.round_windows) m = a.round_windows;
+    // a chain that is building its score leaves these windows when tracking starts, track_after - score hits on
+    // at the latest (lib/pss_impl.cc:119-126): nothing beyond that window is worth scanning
+    if (!st->is_tracking && st->score > 0 && m > a.track_after - st->score) m = a.track_after - st->score;
+    // Speculation is wasted on a chain that is about to leave its windows again.  One that has just re-aligned
+    // (its average still holds the old peak beside the new one: the next search often misses and resets it,
+    // lib/pss_impl.cc:134-151) gets two windows; one whose average has just been reset tends to fire at once and
+    // to start tracking track_after windows later, so it gets no more than that.
+    if (!st->is_tracking && st->pre_n > 0 && m > 2) m = 2;
+    if (!st->is_tracking && st->ema_zero && m > a.track_after + 1) m = a.track_after + 1;
     if (m > kScanMaxRound - st->pre_n) m = kScanMaxRound - st->pre_n;
     n[r] = m > 0 ? (int)m : 0;
   }
@@ -261,8 +284,9 @@ __global__ void lt_plan_kernel(PlanArgs a)
     bool leader = true;
     for (int q = 0; q < r; ++q) leader = leader && !(n[q] > 0 && plain[q] && plain[r] && first[q] == first[r] && stride[q] == stride[r]);
     if (!leader) continue;
-    const int j = atomicAdd(a.n_jobs, 1);
     const ChainState *st = a.state + c * 3 + r;
+    const bool is_long = st->pre_n + n[r] > a.round_windows / 2;
+    const int j = is_long ? atomicAdd(a.n_jobs, 1) : a.jobs_cap - 1 - atomicAdd(a.n_jobs + 1, 1);
     ScanJob job;
     job.pos_a = st->pre_pos; job.stride_a = st->pre_stride; job.n_a = st->pre_n;
     job.pos_b = first[r]; job.stride_b = stride[r]; job.n_b = n[r];
@@ -278,6 +302,12 @@ __global__ void lt_plan_kernel(PlanArgs a)
       }
     a.jobs[j] = job;
   }
+}
+
+__global__ void lt_plan_kernel(PlanArgs a)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < a.n_channels) plan_channel(a, c);
 }
 
 // ---------------------------------------------------------------- resolve: general_work on the scanned windows
@@ -300,11 +330,12 @@ struct ResolveArgs {
   float psr_threshold;
   int track_after;
   int track_every;
+  PlanArgs next;      // the plan of the next round, made by the same launch (next.jobs / next.n_jobs: the other buffers)
+  int plan_next;
 };
 
-__global__ __launch_bounds__(64) void lt_resolve_kernel(ResolveArgs a)
+__device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, int lane)
 {
-  const int chain = blockIdx.x, lane = threadIdx.x;
   ChainState *st = a.state + chain;
   if (st->scan_job < 0) return;
   const ScanJob job = a.jobs[st->scan_job];
@@ -350,7 +381,51 @@ __global__ __launch_bounds__(64) void lt_resolve_kernel(ResolveArgs a)
   int used = 0;          // windows of the job whose search has been executed
   bool ema_reset = false, stop_run = false, need_chain = false;
   run_timer_calls();
-  for (int k = 0; k < job.n_b; ++k) {
+  // ---- an idle chain (lib/pss_impl.cc:134-135: a miss with score 0 changes nothing but d_psr, the ring and the
+  // position): all the misses up to the first window that fires, one lane each
+  int k0 = 0;
+  if (!is_tracking && score == 0 && !tracking_lost && job.stride_b == 1 && pos == job.pos_b) {
+    int fit = job.n_b;
+    if (pos > limit) fit = 0;
+    else if ((limit - pos) / kHalfFrame + 1 < fit) fit = (int)((limit - pos) / kHalfFrame + 1);
+    if (a.rec_cap - nrec < fit) fit = a.rec_cap - nrec;
+    const bool valid = lane < fit;
+    const bool fire = valid && (!wr.exact || wr.psr > a.psr_threshold);
+    const unsigned long long fm = __ballot(fire);
+    const int n_miss = fm ? __builtin_ctzll(fm) : fit;
+    if (n_miss > 0) {
+      const bool miss = lane < n_miss;
+      float pm = miss ? wr.psr : -FLT_MAX; // d_psr_max as an inclusive prefix maximum
+      if (!(pm == pm)) pm = -FLT_MAX;      // a NaN never raises it
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(pm, d);
+        if (lane >= d) pm = fmaxf(pm, o);
+      }
+      const float my_max = fmaxf(psr_max, pm);
+      if (miss) {
+        lt_record r;
+        r.in_pos = pos + (int64_t)lane * kHalfFrame; r.out_pos = -1; r.channel = channel; r.n_id_2 = n_id_2;
+        r.call_idx = call_base + nrec + lane; r.flags = LT_F_SEARCHED; r.peak_pos = wr.peak_pos; r.score = 0;
+        r.psr = wr.psr; r.peak_value = wr.peak_value; r.cfo = 0.f; r.mean_cfo = 0.f;
+        r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+        r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+        r.psr_max = my_max; r.timer = a.track_every;
+        recs[nrec + lane] = r;
+        st->psr_data[(psr_i + (uint32_t)lane) % kMovingAvgSz] = wr.psr; // d_psr_data ring (lib/pss_impl.cc:166)
+      }
+      psr_max = __shfl(my_max, n_miss - 1);
+      psr = __shfl(wr.psr, n_miss - 1);
+      peak_pos = __shfl(wr.peak_pos, n_miss - 1);
+      timer = a.track_every;
+      psr_i += (uint32_t)n_miss;
+      nrec += n_miss;
+      pos += (int64_t)n_miss * kHalfFrame;
+      used = n_miss;
+      k0 = n_miss;
+    }
+  }
+  for (int k = k0; k < job.n_b; ++k) {
     const int64_t pk = job.pos_b + (int64_t)k * job.stride_b * kHalfFrame;
     if (ema_reset || pos != pk || (is_tracking ? a.track_every + 1 : 1) != job.stride_b) break; // off the job's windows
     if (is_tracking && timer != 0) break; // (the calls before the search did not all fit)
@@ -448,6 +523,19 @@ __global__ __launch_bounds__(64) void lt_resolve_kernel(ResolveArgs a)
       st->pre_n = used;
     } // (used == 0: nothing consumed, the chain's average is described as before)
   }
+}
+
+// One workgroup per channel, one wave per chain; when the three chains are through, the channel's jobs of the
+// next round are planned by the same launch.
+__global__ __launch_bounds__(192) void lt_resolve_kernel(ResolveArgs a)
+{
+  const int c = blockIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  resolve_chain(a, c * 3 + w, lane);
+  if (!a.plan_next) return;
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x == 0) plan_channel(a.next, c);
 }
 
 } // namespace lt

@@ -62,8 +62,9 @@ int main(int argc, char **argv)
   int *dnj;
   CK(hipMalloc(&djobs, sizeof(ScanJob) * n_ch));
   CK(hipMemcpy(djobs, jobs.data(), sizeof(ScanJob) * n_ch, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dnj, sizeof(int)));
-  CK(hipMemcpy(dnj, &n_ch, sizeof(int), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dnj, 2 * sizeof(int)));
+  const int njj[2] = {n_ch, 0};
+  CK(hipMemcpy(dnj, njj, sizeof njj, hipMemcpyHostToDevice));
   ChainState *dst;
   CK(hipMalloc(&dst, sizeof(ChainState) * n_ch * 3));
   CK(hipMemset(dst, 0, sizeof(ChainState) * n_ch * 3));
@@ -76,12 +77,12 @@ int main(int argc, char **argv)
   CK(hipMalloc(&dparts, sizeof(StripPartial) * (size_t)n_ch * 3 * kScanMaxRound * kStrips));
   ScanArgs a;
   a.iq = diq; a.ch_stride = n; a.hist = nullptr; a.hist_stride = 0; a.t0 = 0; a.n = n; a.hist_len = 0;
-  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.tab = dtab;
+  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.tab = dtab; a.jobs_cap = n_ch;
   unsigned long long *dprof;
   CK(hipMalloc(&dprof, 64));
   CK(hipMemset(dprof, 0, 64));
   a.prof = dprof;
-  const int grid = ((n_ch + 7) / 8) * 8 * kScanWgPerJob;
+  const int grid = (((n_ch + 7) / 8) * 8 + 8) * kScanWgPerJob;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
