@@ -5,6 +5,7 @@ missing, or no gfx950 device is usable, they raise.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -69,6 +70,16 @@ def lib():
         raise LtError(
             f"{LIB_PATH} is missing: build it with `make -C {_HERE}` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch ships a HIP runtime of its own.  The two coexist in one process only in this order: PyTorch's
+    # libraries loaded and its device context up first, then this library (observed on ROCm 7.2 / torch 2.10: any
+    # other interleaving leaves one of the two without a device).  So if the process uses torch, bring it up now.
+    if "torch" in sys.modules:
+        try:
+            _torch = sys.modules["torch"]
+            if _torch.cuda.is_available():
+                _torch.cuda.init()
+        except Exception:  # torch without a usable GPU: nothing to order against
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
     pp = C.POINTER(vp)
@@ -390,7 +401,7 @@ class Decim:
         self.decimation = decimation
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:  # (lib is None while the interpreter shuts down)
             lib().lt_decim_free(self._h)
             self._h = None
 

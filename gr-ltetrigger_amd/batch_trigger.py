@@ -1,6 +1,6 @@
 """Batched counterpart of downlink_trigger_c: many channels at once on the device.
 
-The pss -> sss part of every chain runs in lt_chain_kernel (one launch for the whole batch); the
+The pss -> sss part of every chain runs on the device (lt_batch_run: grid scan, per-chain and per-record kernels); the
 mib stage replays lib/mib_impl.cc:97-183 on the host over the returned records, decoding PBCH on
 the CFO-corrected first subframe of tagged half-frames (lt_cfo_correct reproduces the kernel's
 rotation bit for bit)."""
@@ -42,6 +42,9 @@ class BatchTrigger:
         if iq_tensor.dtype != torch.complex64 or not iq_tensor.is_contiguous():
             raise ValueError("need a contiguous complex64 tensor")
         n = iq_tensor.shape[1]
+        if stream is None:
+            # the stream the tensor's producer ran on: the library's own stream would not be ordered behind it
+            stream = torch.cuda.current_stream(iq_tensor.device).cuda_stream
         self.batch.reset()
         self.batch.run_device(torch.view_as_real(iq_tensor).data_ptr(), n, stream)
         recs = self.batch.collect()
