@@ -73,7 +73,7 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
 // exponential average only (a window the scan has already turned into a record).  Contains workgroup
 // barriers; `buf` alternates between calls.
 __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane,
-                                                     float (&ema)[kStripRegs], int &buf, bool resolve)
+                                                     ema_t &ema, int &buf, bool resolve)
 {
   fft::c32 *e = L.E + w * fft::kScratchW;
   strip_fft<false>(lane, x, L.TW1, L.TW2, e);
@@ -179,11 +179,11 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   // ---- load state.  The average is avg[ema_sel] (or all zeros after srslte_pss_reset) run through the pre_n
   // windows of a scan round the chain did not follow to its end: brought up to date before the first search,
   // by the same search call as every other window.
-  float ema[kStripRegs];
+  ema_t ema;
   float *avg = st->avg[st->ema_sel];
   if (st->ema_zero) {
 #pragma unroll
-    for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+    for (int r = 0; r < 16; ++r) ema[r] = r < kStripRegs ? 0.f : -FLT_MAX;
   } else {
     strip_ema_load(avg, w, lane, ema);
   }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_find_kernel(const v2f *__res
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   Capture cap;
   cap.iq = win; cap.hist = nullptr; cap.t0 = 0; cap.n = kHalfFrame; cap.hist_len = 0;
-  float ema[kStripRegs];
+  ema_t ema;
   strip_ema_load(avg, w, lane, ema);
   chain_lds_init(L, tab, n_id_2);
   __syncthreads();

@@ -29,6 +29,10 @@ constexpr int kStripIn0 = -(kStripHalo + kSymbolSz); // window sample of block e
 static_assert(kStrips * kStripPitch >= kNLags, "strips must cover every lag");
 static_assert(kStripHalo >= 32 && 64 * kStripRegs - kStripHalo - kStripPitch >= 32, "halo must hold the lobe walk");
 
+// A strip's exponential average: 14 live registers per lane, held as one 16-register tuple so that "the register
+// the peak sits in" -- a wave-uniform but run-time index -- is a single indexed register move, not a chain of selects.
+typedef float ema_t __attribute__((ext_vector_type(16)));
+
 constexpr uint32_t kPartWide = 1u;  // lobe not closed inside the strip's 64-lag neighbourhood: exact path needed
 
 // What a strip tells the resolver about one window (32 bytes, one per (chain, window, strip)).
@@ -57,51 +61,52 @@ __device__ __forceinline__ float wave_prev(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // wave_ror:1
 }
 
-// e[r] = average of lag c0 + lane + 64 r.  Wave-uniform result in `out` (every lane holds it).
-__device__ __forceinline__ void strip_resolve(const float (&e)[kStripRegs], int s, int lane, StripPartial &out)
+// e[r] = average of lag c0 + lane + 64 r (r < 14; e[14], e[15] = -FLT_MAX).  Wave-uniform result in `out` (every
+// lane holds it).  Works on the registers in place -- four of them are patched and put back -- because a masked
+// copy of the tuple would cost 16 moves per window.
+__device__ __forceinline__ void strip_resolve(ema_t &e, int s, int lane, StripPartial &out)
 {
   const int c0 = kStripPitch * s - kStripHalo;
-  // owned and valid lags: offsets [41, 852) of the computed range, lag < 9726 (strip 11 ends at offset 845)
+  // owned and valid lags: offsets [41, 852) of the computed range, lag < 9726 (strip 11 ends at offset 845):
+  // the halo lags in registers 0 and 13 sit out the two maxima
   const bool own0 = lane >= kStripHalo;
   const int own13_end = (s == kStrips - 1) ? (kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13)
                                            : (kStripHalo + kStripPitch - 64 * 13);
   const bool own13 = lane < own13_end;
-  float em[kStripRegs];
+  const float full0 = e[0], full13 = e[13];
+  e[0] = own0 ? full0 : -FLT_MAX;
+  e[13] = own13 ? full13 : -FLT_MAX;
+  // 1. maximum over the owned lags, by groups of three registers, and where it sits (first in lag order:
+  // smallest register, then lane): first group that holds it, first register of that group
+  float g[5];
 #pragma unroll
-  for (int r = 0; r < kStripRegs; ++r) em[r] = e[r];
-  em[0] = own0 ? e[0] : -FLT_MAX;
-  em[13] = own13 ? e[13] : -FLT_MAX;
-  // 1. maximum over the owned lags and where it sits (first in lag order: smallest register, then lane)
-  float m = em[0];
+  for (int i = 0; i < 5; ++i) g[i] = fmaxf(fmaxf(e[3 * i], e[3 * i + 1]), e[3 * i + 2]); // (e[14] = -FLT_MAX)
+  const float M1 = wave_max_f(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
+  int gi = 0;
 #pragma unroll
-  for (int r = 1; r < kStripRegs; ++r) m = fmaxf(m, em[r]);
-  const float M1 = wave_max_f(m);
-  int r_p = 0;
-  uint64_t bal = 0;
-#pragma unroll
-  for (int r = kStripRegs - 1; r >= 0; --r) {
-    const uint64_t b = __ballot(em[r] == M1);
-    if (b) {
-      r_p = r;
-      bal = b;
-    }
-  }
+  for (int i = 4; i >= 0; --i)
+    if (__ballot(g[i] == M1)) gi = i;
+  gi = __builtin_amdgcn_readfirstlane(gi);
+  const float c0v = e[3 * gi], c1v = e[3 * gi + 1], c2v = e[3 * gi + 2]; // (run-time register index, wave-uniform)
+  const uint64_t b0 = __ballot(c0v == M1), b1 = __ballot(c1v == M1), b2 = __ballot(c2v == M1);
+  uint64_t bal = b0 ? b0 : b1 ? b1 : b2;
+  int r_p = 3 * gi + (b0 ? 0 : b1 ? 1 : 2);
   uint32_t flags = 0;
-  if (!bal) { // only a NaN can do that: outside the contract, but stay in bounds
+  if (!bal || r_p >= kStripRegs) { // only a NaN can do that: outside the contract, but stay in bounds
     bal = 1ull << kStripHalo;
+    r_p = 0;
     flags = kPartWide;
   }
+  r_p = __builtin_amdgcn_readfirstlane(r_p);
   const int l_p = __builtin_ctzll(bal);
   const int p1 = c0 + l_p + 64 * r_p;
   // 2. the lags p1 - 32 .. p1 + 31 as one rotated row: lane L holds offset (L - l_p) wrapped to [-32, 32).
-  // Offsets that fall off this register's 64 lanes come from the register before (l_p < 32) or after it.
-  const int r_b = (l_p < 32) ? r_p - 1 : r_p + 1; // exists whenever a lane needs it (the peak is an owned lag)
-  float rowA = e[0], rowB = e[0];
-#pragma unroll
-  for (int r = 1; r < kStripRegs; ++r) {
-    rowA = (r_p == r) ? e[r] : rowA;
-    rowB = (r_b == r) ? e[r] : rowB;
-  }
+  // Offsets that fall off this register's 64 lanes come from the register before (l_p < 32) or after it
+  // (which exists whenever a lane needs it: the peak is an owned lag).
+  const int r_b = (l_p < 32) ? (r_p > 0 ? r_p - 1 : 1) : (r_p < kStripRegs - 1 ? r_p + 1 : kStripRegs - 2);
+  const float mA = e[r_p], mB = e[r_b]; // as patched: what the second maximum has to put back
+  const float rowA = (r_p == 0) ? full0 : (r_p == kStripRegs - 1) ? full13 : mA;
+  const float rowB = (r_b == 0) ? full0 : (r_b == kStripRegs - 1) ? full13 : mB;
   const bool use_b = (l_p < 32) ? (lane >= l_p + 32) : (lane < l_p - 32);
   const float row = use_b ? rowB : rowA;
   const float nxt = wave_next(row), prv = wave_prev(row);
@@ -120,23 +125,26 @@ __device__ __forceinline__ void strip_resolve(const float (&e)[kStripRegs], int 
   else if (ml) j_l = 1 + __builtin_clzll(ml);
   else flags |= kPartWide;
   const int lb = p1 - j_l, ub = p1 + j_r;
-  // 3. maximum over the owned lags outside [lb, ub).  The lobe's lags sit in registers r_p / r_b of the
-  // lanes at offsets [-j_l, j_r); every other register of those lanes, and everything in the other lanes, counts.
+  // 3. maximum over the owned lags outside [lb, ub).  The lobe's lags sit in registers r_p / r_b of the lanes
+  // at offsets [-j_l, j_r): knock those out, take the maximum again, put them back.
   const uint64_t lobe_rot = ((1ull << j_r) - 1ull) | (j_l ? (~0ull << (64 - j_l)) : 0ull);
   const uint64_t lobe = rotl64(lobe_rot, l_p);
   const bool in_lobe = (lobe >> lane) & 1ull;
-  const float rowA_out = (in_lobe && !use_b) ? -FLT_MAX : ((r_p == 0) ? em[0] : (r_p == 13) ? em[13] : rowA);
-  const float rowB_out = (in_lobe && use_b) ? -FLT_MAX : ((r_b == 0) ? em[0] : (r_b == 13) ? em[13] : rowB);
-  float so = fmaxf(rowA_out, (r_b >= 0 && r_b < kStripRegs) ? rowB_out : -FLT_MAX);
+  e[r_p] = (in_lobe && !use_b) ? -FLT_MAX : mA;
+  e[r_b] = (in_lobe && use_b) ? -FLT_MAX : mB;
 #pragma unroll
-  for (int r = 0; r < kStripRegs; ++r) so = fmaxf(so, (r == r_p || r == r_b) ? -FLT_MAX : em[r]);
-  const float S = wave_max_f(so);
+  for (int i = 0; i < 5; ++i) g[i] = fmaxf(fmaxf(e[3 * i], e[3 * i + 1]), e[3 * i + 2]);
+  const float S = wave_max_f(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
+  e[r_p] = mA;
+  e[r_b] = mB;
+  e[0] = full0;
+  e[13] = full13;
   out.m1 = M1;
   out.p1 = p1;
   out.s = S;
   out.lb = lb;
   out.ub = ub;
-  out.a0 = (s == 0) ? rlane(e[0], kStripHalo) : 0.f;
+  out.a0 = (s == 0) ? rlane(full0, kStripHalo) : 0.f;
   out.flags = flags;
   out.pad = 0;
 }
@@ -284,7 +292,7 @@ __device__ __forceinline__ void strip_fft_ab(int lane, fft::c32 (&x)[16], const 
 // oracle/lte_oracle.c:289-293).  Lags outside [0, 9726) stay 0.
 __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f *spec,
                                                   const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e,
-                                                  float (&ema)[kStripRegs])
+                                                  ema_t &ema)
 {
 #pragma unroll
 #ifndef LT_ABL_NO_SPEC
@@ -311,7 +319,7 @@ __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)
 // diagnostics build: the same with shader-clock stamps between the stages (tools/scan_bench.hip)
 __device__ __forceinline__ void strip_root_update_prof(int s, int lane, fft::c32 (&v)[16], const v2f *spec,
                                                        const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e,
-                                                       float (&ema)[kStripRegs], unsigned long long (&pr)[8], unsigned long long &tp)
+                                                       ema_t &ema, unsigned long long (&pr)[8], unsigned long long &tp)
 {
 #define LT_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
@@ -341,16 +349,18 @@ __device__ __forceinline__ void strip_root_update_prof(int s, int lane, fft::c32
 #endif
 
 // the strip's slice of conv_output_avg (natural lag order in HBM) <-> registers
-__device__ __forceinline__ void strip_ema_load(const float *__restrict__ avg, int s, int lane, float (&ema)[kStripRegs])
+__device__ __forceinline__ void strip_ema_load(const float *__restrict__ avg, int s, int lane, ema_t &ema)
 {
   const int c0 = kStripPitch * s - kStripHalo;
+  ema[14] = -FLT_MAX; // (the two spare registers of the tuple never win a maximum)
+  ema[15] = -FLT_MAX;
 #pragma unroll
   for (int r = 0; r < kStripRegs; ++r) {
     const int lag = c0 + lane + 64 * r;
     ema[r] = (lag >= 0 && lag < kNLags) ? avg[lag] : 0.f;
   }
 }
-__device__ __forceinline__ void strip_ema_store(float *__restrict__ avg, int s, int lane, const float (&ema)[kStripRegs])
+__device__ __forceinline__ void strip_ema_store(float *__restrict__ avg, int s, int lane, const ema_t &ema)
 {
   const int c0 = kStripPitch * s - kStripHalo;
 #pragma unroll

@@ -163,13 +163,13 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     __builtin_amdgcn_s_setprio(LT_ROOT_PRIO);
 #endif
     fft::c32 x[16]; // spectrum, then lags
-    float ema[kStripRegs];
+    ema_t ema;
     const int chain = job.channel * 3 + root;
     ChainState *st = a.state + chain;
     const int sel = st->ema_sel;
     if (job.zero) {
 #pragma unroll
-      for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+      for (int r = 0; r < 16; ++r) ema[r] = r < kStripRegs ? 0.f : -FLT_MAX;
     } else {
       strip_ema_load(st->avg[sel], strip, lane, ema);
     }

@@ -54,7 +54,7 @@ int main(int argc, char **argv)
     jobs[c].pos_a = 0; jobs[c].stride_a = 1; jobs[c].n_a = 0;
     jobs[c].pos_b = 0; jobs[c].stride_b = 1; jobs[c].n_b = n_win;
     jobs[c].channel = c;
-    jobs[c].roots = 7;
+    jobs[c].roots = argc > 3 ? atoi(argv[3]) : 7;
     jobs[c].zero = 1;
     jobs[c].pad = 0;
   }
