@@ -273,6 +273,8 @@ __global__ __launch_bounds__(64) void lt_cfo_ring_kernel(CpArgs a)
     const unsigned long long ran = __ballot((flags & LT_F_SSS_RAN) != 0), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
     unsigned long long events = ran | lost;
     float mine = 0.f;
+    double my_acc = 0.0; // narrow mode: this lane's record's sum and count; the division waits until after the walk
+    uint32_t my_n = 0;
     while (events) {
       const int j = __builtin_ctzll(events);
       events &= events - 1;
@@ -291,21 +293,27 @@ __global__ __launch_bounds__(64) void lt_cfo_ring_kernel(CpArgs a)
           emax = e > emax ? e : emax;
           if (emax - emin > 20u || emax >= 255u) narrow = false;
         }
-        float mc;
         if (narrow) {
           if (cfo_i >= (uint32_t)kMovingAvgSz) acc -= (double)ring[slot]; // the entry this call overwrites
           acc += (double)cj;
-          mc = (float)(acc / (double)npts);
+          if (lane == j) {
+            my_acc = acc;
+            my_n = npts;
+          }
         } else {
-          mc = moving_avg_wave(ring, cfo_i + 1, slot, cj);
+          const float mc = moving_avg_wave(ring, cfo_i + 1, slot, cj);
+          if (lane == j) {
+            mine = mc;
+            my_n = 0;
+          }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) ring[slot] = cj;
         __builtin_amdgcn_wave_barrier();
         cfo_i++;
-        if (lane == j) mine = mc;
       }
     }
+    if (my_n) mine = (float)(my_acc / (double)my_n);
     if (i < count && (flags & LT_F_SSS_RAN)) recs[i].mean_cfo = mine;
   }
   for (int i = lane; i < kMovingAvgSz; i += 64) st->cfo_data[i] = ring[i];

@@ -370,12 +370,27 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
   };
   // the calls of a tracked chain between two searches (lib/pss_impl.cc:170-172, 184-204 with frame_start = 0)
   auto run_timer_calls = [&]() {
-    while (is_tracking && timer > 0 && pos <= limit && nrec < a.rec_cap) {
-      timer--;
-      put(pos, pos, LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING, kSlotLen, 0.f);
-      n_emits++;
-      pos += kHalfFrame;
+    if (!(is_tracking && timer > 0)) return;
+    int nb = timer; // one record per call, one lane each (timer <= track_every; more than 64 take several turns)
+    if (pos > limit) nb = 0;
+    else if ((limit - pos) / kHalfFrame + 1 < nb) nb = (int)((limit - pos) / kHalfFrame + 1);
+    if (a.rec_cap - nrec < nb) nb = a.rec_cap - nrec;
+    for (int idx = lane; idx < nb; idx += 64) {
+      const int64_t p = pos + (int64_t)idx * kHalfFrame;
+      lt_record r;
+      r.in_pos = p; r.out_pos = p; r.channel = channel; r.n_id_2 = n_id_2;
+      r.call_idx = call_base + nrec + idx; r.flags = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
+      r.peak_pos = kSlotLen; r.score = score;
+      r.psr = psr; r.peak_value = 0.f; r.cfo = 0.f; r.mean_cfo = 0.f;
+      r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+      r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+      r.psr_max = psr_max; r.timer = timer - 1 - idx;
+      recs[nrec + idx] = r;
     }
+    timer -= nb;
+    nrec += nb;
+    n_emits += nb;
+    pos += (int64_t)nb * kHalfFrame;
   };
 
   int used = 0;          // windows of the job whose search has been executed
