@@ -261,20 +261,18 @@ def main():
     if rank == 0:
         value = sharding.aggregate_msamp_per_s(world, n_ch, n, args.steps, elapsed)
         algo_bytes = ALGO_BYTES_PER_SAMPLE * n_ch * n  # per launch and GPU
-        # what each stage has to read and write at least ("kernel I/O", not the path's algorithmic bytes):
-        # the scan reads every sample of the searched windows once and writes 12 x 32 B of partial results per
-        # (chain, window) plus one 96-byte record per miss; the per-chain kernel reads the 9600-sample window of
-        # every call it searches and the 128-sample PSS symbol of every tracked half-frame and writes a record per
-        # call; the per-record kernels read 480 + 128 samples per tracked half-frame and rewrite the records
+        # what each stage has to read and write at least ("kernel I/O", not the path's algorithmic bytes): the scan
+        # rounds read the 9600-sample window of every search once and write 12 x 32 B of partial results per searched
+        # window plus one 96-byte record per call; the per-chain kernel only sees chains the rounds could not finish
+        # (none in this workload); the per-record kernels read 128 + 480 + 128 samples per tracked half-frame and
+        # rewrite the records
         searched = sum(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
         sss_ran = sum(int(((r["flags"] & lt.F_SSS_RAN) != 0).sum()) for r in recs)
-        misses = sum(int((r["flags"] == lt.F_SEARCHED).sum()) for r in recs)
         calls = sum(len(r) for r in recs)
-        n_win = n // 9600
         io = {
-            "grid_scan": algo_bytes + 3.0 * n_ch * n_win * 12 * 32 + misses * 96.0,
-            "lt_chain_kernel": (searched - misses) * 9600 * 8.0 + sss_ran * 128 * 8.0 + (calls - misses) * 96.0,
-            "per_record": sss_ran * (480 + 128) * 8.0 + calls * 2 * 96.0,
+            "grid_scan": searched * 9600 * 8.0 + searched * 12 * 32.0 + calls * 96.0,
+            "lt_chain_kernel": 0.0,
+            "per_record": sss_ran * (128 + 480 + 128) * 8.0 + calls * 3 * 96.0,
         }
         traffic, traffic_src = load_traffic()
         kernels = []
@@ -286,7 +284,7 @@ def main():
                 t = sum(traffic.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in STAGE_KERNELS[name])
             kernels.append({"stage": name, "kernels": list(STAGE_KERNELS[name]), "ms": round(float(ms), 4),
                             "kernel_io_bytes_per_launch": io[name],
-                            "kernel_io_gbs": round(io[name] / (ms * 1e-3) / 1e9, 2), "traffic": t})
+                            "kernel_io_gbs": round(io[name] / (ms * 1e-3) / 1e9, 2) if io[name] else None, "traffic": t})
         dom = max(kernels, key=lambda k: k["ms"])
         traffic_total = sum(k["traffic"] for k in kernels) if traffic is not None else None
         out = {

@@ -1,15 +1,4 @@
-// Half-wave 1024-point complex FFT used by the overlap-save matched filter.
-//
-// 32 lanes transform one 1024-sample block, 32 values per lane (1024 = 32 x 32), so a wave64 carries
-// two independent transforms and one transform needs a single trip through LDS:
-//
-//   element index i = lane + 32 * reg                      (same layout on input and output)
-//   stage 1  radix-32 over reg:  A[k1] = sum_n1 x[32 n1 + m] W32^(n1 k1),   times W1024^(m k1)
-//   exchange                       E[k1][m]  ->  lane k1 reads E[k1][0..31]
-//   stage 2  radix-32 over reg:  X[k1 + 32 q] = sum_m E[k1][m] W32^(m q)    (lane k1, reg q)
-//
-// Because output element k again sits at lane k % 32, register k / 32, the inverse transform
-// (same code, conjugated twiddles) can be applied to the product with the filter spectrum directly.
+// 1024-point complex FFT of the overlap-save matched filter, one transform per wave64: 64 lanes x 16 values.
 // Plain C++ over a 2-float vector type and an explicit "LDS" pointer, so that
 // tests/hostcheck/fft_host_check.cpp can run it lane by lane on the CPU.
 #pragma once
@@ -35,8 +24,6 @@ namespace fft {
 typedef float c32 __attribute__((ext_vector_type(2)));
 
 constexpr int kN = 1024;
-constexpr int kRow = 33;             // row stride of the exchange (32 + 1: conflict-free both ways)
-constexpr int kScratch = 32 * kRow;  // c32 entries of scratch per transform (8448 B)
 
 // Complex products written so that every sign lives in a constant operand of a packed FMA (hipcc
 // turns a negated *variable* operand into v_xor + v_mov, but folds constants for free).
@@ -115,66 +102,9 @@ template <int S, bool kInv> LT_HD void fft16(c32 *v)
                  v[S * (k1 + 8)], v[S * (k1 + 12)]);
 }
 
-// 32-point DFT in registers, natural order in and out: two 16-point DFTs over the even and the odd
-// elements, W32^k on the odd half, radix-2 combine (X[k], X[k+16] = E[k] +- W32^k O[k]).
-template <bool kInv> LT_HD void fft32(c32 v[32])
-{
-  fft16<2, kInv>(v);     // even elements: E[k] lands in v[2 k]
-  fft16<2, kInv>(v + 1); // odd elements:  O[k] lands in v[2 k + 1]
-  const c32 w[16] = {{1.f, 0.f},
-                     {0.98078528040323044f, -0.19509032201612826f},
-                     {0.92387953251128674f, -0.38268343236508977f},
-                     {0.83146961230254524f, -0.55557023301960222f},
-                     {0.70710678118654752f, -0.70710678118654752f},
-                     {0.55557023301960222f, -0.83146961230254524f},
-                     {0.38268343236508977f, -0.92387953251128674f},
-                     {0.19509032201612826f, -0.98078528040323044f},
-                     {0.f, -1.f},
-                     {-0.19509032201612826f, -0.98078528040323044f},
-                     {-0.38268343236508977f, -0.92387953251128674f},
-                     {-0.55557023301960222f, -0.83146961230254524f},
-                     {-0.70710678118654752f, -0.70710678118654752f},
-                     {-0.83146961230254524f, -0.55557023301960222f},
-                     {-0.92387953251128674f, -0.38268343236508977f},
-                     {-0.98078528040323044f, -0.19509032201612826f}};
-  c32 lo[16], hi[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const c32 e = v[2 * k];
-    const c32 o = (k == 0) ? v[1] : cmulc(v[2 * k + 1], cw<kInv>(w[k]));
-    lo[k] = e + o;
-    hi[k] = e - o;
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    v[k] = lo[k];
-    v[k + 16] = hi[k];
-  }
-}
-
-// tw[reg * 32 + lane] = W1024^(reg * lane), reg, lane = 0..31 (c32, 8 KB).
-// One 1024-point DFT (forward, or unnormalised inverse) by the 32 lanes of a half-wave; l = lane
-// within the half (0..31), v[reg] = element l + 32 reg on entry and on exit, e = this transform's
-// scratch (kScratch entries).  All 32 lanes must execute the two stages in lock step.
-template <bool kInv> LT_HD void fft1024_stage1(int l, c32 v[32], const c32 *tw, c32 *e)
-{
-  fft32<kInv>(v);
-#pragma unroll
-  for (int k1 = 0; k1 < 32; ++k1) {
-    if (k1) v[k1] = cmul<kInv>(v[k1], tw[k1 * 32 + l]);
-    e[k1 * kRow + l] = v[k1];
-  }
-}
-template <bool kInv> LT_HD void fft1024_stage2(int l, c32 v[32], const c32 *e)
-{
-#pragma unroll
-  for (int m = 0; m < 32; ++m) v[m] = e[l * kRow + m];
-  fft32<kInv>(v);
-}
-
-// ---- full-wave variant (bulk lag-metric kernel): 64 lanes transform one 1024-sample block, 16 values
-// per lane (1024 = 16 x 16 x 4), so a lane needs half the registers of the half-wave form and four
-// waves per SIMD fit.  Element index i = lane + 64 * reg on input AND output.
+// 64 lanes transform one 1024-sample block, 16 values per lane (1024 = 16 x 16 x 4).  Element index
+// i = lane + 64 * reg on input AND output, so the inverse transform (same code, conjugated twiddles) can be
+// applied to the product with the filter spectrum directly.
 //   stage A  radix-16 over reg:  a[k1] = sum_r x[l + 64 r] W16^(r k1),  times W1024^(l k1)
 //   exchange 1                   E1[k1][l]  ->  lane (k1, c) = 4 k1 + c reads E1[k1][c + 4 s], s = 0..15
 //   stage B  radix-16 over s:    b[t] = sum_s E1[k1][c + 4 s] W16^(s t),  times W64^(c t)

@@ -101,12 +101,6 @@ void build_device_tables(DeviceTables *t)
     t->dft128_sin[e] = std::sin(ph);
   }
 
-  for (int reg = 0; reg < 32; ++reg)
-    for (int l = 0; l < 32; ++l) {
-      const double ph = -2.0 * kPi * (double)((l * reg) % 1024) / 1024.0;
-      t->fft_tw[reg * 32 + l].re = (float)std::cos(ph);
-      t->fft_tw[reg * 32 + l].im = (float)std::sin(ph);
-    }
   for (int k1 = 0; k1 < 16; ++k1)
     for (int l = 0; l < 64; ++l) {
       const double ph = -2.0 * kPi * (double)(l * k1) / 1024.0;
@@ -129,7 +123,6 @@ void build_device_tables(DeviceTables *t)
       }
       t->pss_spec[r][k].re = (float)(sr / 1024.0);
       t->pss_spec[r][k].im = (float)(si / 1024.0);
-      pair_entry(t->pss_spec2[r][k], t->pss_spec[r][k].re, t->pss_spec[r][k].im);
     }
 
   float s[31], c[31], z[31];

@@ -30,16 +30,13 @@ struct DeviceTables {
   int32_t nid1_table[30][30]; // T[m0][m1-1] = N_id_1, zero elsewhere
   // the same m-sequences as sign masks: bit i set <=> element i is -1
   uint32_t sss_s_mask, sss_z_mask, sss_c0_mask[3], sss_c1_mask[3];
-  // overlap-save matched filter (csrc/lt_fft.h): twiddles W1024^(reg * lane) as [reg][lane], and
-  // the 1024-point spectrum of the zero-padded filter divided by 1024, natural order
-  // (element k = lane + 32 reg is what lane `lane` holds in register `reg`)
-  cf32 fft_tw[32 * 32];
+  // overlap-save matched filter (csrc/lt_fft.h): the 1024-point spectrum of the zero-padded filter divided by
+  // 1024, natural order (element k = lane + 64 reg is what lane `lane` holds in register `reg`), and the
+  // transform's twiddles W1024^(l k1) as [k1][l] (16 x 64), W64^(c t) as [t][c] (16 x 4), every entry as the pair
+  // (w, j w) = (re, im, -im, re)
   cf32 pss_spec[3][1024];
-  // full-wave FFT of the bulk lag-metric kernel: W1024^(l k1) as [k1][l] (16 x 64), W64^(c t) as
-  // [t][c] (16 x 4) and the filter spectra / 1024, every entry as the pair (w, j w) = (re, im, -im, re)
   float fft_tw1[16 * 64][4];
   float fft_tw2[16 * 4][4];
-  float pss_spec2[3][1024][4];
 };
 
 void build_device_tables(DeviceTables *t);

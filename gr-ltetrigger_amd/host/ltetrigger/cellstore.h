@@ -4,7 +4,7 @@
 #include <memory>
 #include <vector>
 
-#include "../runtime.h"
+#include "gr_api.h"
 #include "api.h"
 
 namespace gr {

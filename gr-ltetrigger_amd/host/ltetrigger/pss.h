@@ -4,7 +4,7 @@
 #pragma once
 #include <memory>
 
-#include "../runtime.h"
+#include "gr_api.h"
 #include "api.h"
 
 namespace gr {

@@ -1,5 +1,5 @@
-// CPU emulation of the half-wave FFT-1024 of csrc/lt_fft.h: the 32 lanes are run one after the
-// other inside each stage (the stages are separated by one LDS exchange on the device).
+// CPU emulation of the FFT-1024 of csrc/lt_fft.h: the 64 lanes are run one after the other inside each
+// stage (the stages are separated by LDS exchanges on the device).
 // Reads 1024 complex64 from stdin; writes the forward transform in natural order, then the
 // unnormalised inverse transform of that result (exercises "output layout == input layout").
 #include <cmath>
@@ -10,21 +10,7 @@
 
 using namespace lt::fft;
 
-template <bool kInv> static void transform(const std::vector<c32> &x, std::vector<c32> &X, const std::vector<c32> &tw)
-{
-  std::vector<c32> e(kScratch);
-  static c32 regs[32][32];
-  for (int l = 0; l < 32; ++l) {
-    for (int r = 0; r < 32; ++r) regs[l][r] = x[l + 32 * r];
-    fft1024_stage1<kInv>(l, regs[l], tw.data(), e.data());
-  }
-  for (int l = 0; l < 32; ++l) fft1024_stage2<kInv>(l, regs[l], e.data());
-  X.assign(kN, c32{0, 0});
-  for (int l = 0; l < 32; ++l)
-    for (int r = 0; r < 32; ++r) X[l + 32 * r] = regs[l][r];
-}
-
-// full-wave variant: 64 lanes x 16 values, two exchanges
+// 64 lanes x 16 values, two exchanges
 template <bool kInv> static void transform_w(const std::vector<c32> &x, std::vector<c32> &X, const std::vector<c32x2> &tw1,
                                              const std::vector<c32x2> &tw2)
 {
@@ -41,37 +27,25 @@ template <bool kInv> static void transform_w(const std::vector<c32> &x, std::vec
     for (int r = 0; r < 16; ++r) X[l + 64 * r] = regs[l][r];
 }
 
-int main(int argc, char **)
+int main()
 {
-  std::vector<c32> x(kN), tw(32 * 32);
+  std::vector<c32> x(kN);
   if (fread(x.data(), sizeof(c32), kN, stdin) != (size_t)kN) return 1;
-  for (int r = 0; r < 32; ++r)
-    for (int l = 0; l < 32; ++l) {
-      const double ph = -2.0 * M_PI * (double)((l * r) % 1024) / 1024.0;
-      tw[r * 32 + l] = c32{(float)cos(ph), (float)sin(ph)};
-    }
   std::vector<c32> X, Y;
-  if (argc > 1) { // any argument: check the full-wave variant instead
-    std::vector<c32x2> tw1(16 * 64), tw2(16 * 4);
-    for (int k1 = 0; k1 < 16; ++k1)
-      for (int l = 0; l < 64; ++l) {
-        const double ph = -2.0 * M_PI * (double)(l * k1) / 1024.0;
-        tw1[k1 * 64 + l] = c32x2{(float)cos(ph), (float)sin(ph), -(float)sin(ph), (float)cos(ph)};
-      }
-    for (int t = 0; t < 16; ++t)
-      for (int c = 0; c < 4; ++c) {
-        const double ph = -2.0 * M_PI * (double)(c * t) / 64.0;
-        tw2[t * 4 + c] = c32x2{(float)cos(ph), (float)sin(ph), -(float)sin(ph), (float)cos(ph)};
-      }
-    transform_w<false>(x, X, tw1, tw2);
-    fwrite(X.data(), sizeof(c32), kN, stdout);
-    transform_w<true>(X, Y, tw1, tw2);
-    fwrite(Y.data(), sizeof(c32), kN, stdout);
-    return 0;
-  }
-  transform<false>(x, X, tw);
+  std::vector<c32x2> tw1(16 * 64), tw2(16 * 4);
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int l = 0; l < 64; ++l) {
+      const double ph = -2.0 * M_PI * (double)(l * k1) / 1024.0;
+      tw1[k1 * 64 + l] = c32x2{(float)cos(ph), (float)sin(ph), -(float)sin(ph), (float)cos(ph)};
+    }
+  for (int t = 0; t < 16; ++t)
+    for (int c = 0; c < 4; ++c) {
+      const double ph = -2.0 * M_PI * (double)(c * t) / 64.0;
+      tw2[t * 4 + c] = c32x2{(float)cos(ph), (float)sin(ph), -(float)sin(ph), (float)cos(ph)};
+    }
+  transform_w<false>(x, X, tw1, tw2);
   fwrite(X.data(), sizeof(c32), kN, stdout);
-  transform<true>(X, Y, tw); // unnormalised inverse of the forward result = 1024 * x
+  transform_w<true>(X, Y, tw1, tw2); // unnormalised inverse of the forward result = 1024 * x
   fwrite(Y.data(), sizeof(c32), kN, stdout);
   return 0;
 }

@@ -1,4 +1,4 @@
-"""CPU check of the half-wave FFT-1024 (csrc/lt_fft.h): the lane-level code is compiled for the host
+"""CPU check of the FFT-1024 (csrc/lt_fft.h): the lane-level code is compiled for the host
 and emulated lane by lane (tests/hostcheck/fft_host_check.cpp), then compared with numpy."""
 import os
 import shutil
@@ -13,8 +13,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang (vector extensions)")
-@pytest.mark.parametrize("variant", ["half_wave", "full_wave"])
-def test_lane_level_fft_matches_numpy(tmp_path, variant):
+def test_lane_level_fft_matches_numpy(tmp_path):
     exe = str(tmp_path / "fft_host_check")
     src = os.path.join(ROOT, "tests", "hostcheck", "fft_host_check.cpp")
     subprocess.check_call([CLANG, "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, src])
@@ -24,8 +23,7 @@ def test_lane_level_fft_matches_numpy(tmp_path, variant):
         if trial == 2:
             x[:] = 0
             x[5] = 1
-        cmd = [exe] + (["w"] if variant == "full_wave" else [])
-        out = subprocess.run(cmd, input=x.tobytes(), capture_output=True, check=True).stdout
+        out = subprocess.run([exe], input=x.tobytes(), capture_output=True, check=True).stdout
         r = np.frombuffer(out, dtype=np.complex64)
         fwd, inv = r[:1024], r[1024:]
         ref = np.fft.fft(x.astype(np.complex128))

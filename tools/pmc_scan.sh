@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / LDS counters of a stand-alone bench binary (run on the GPU box through gpurun): one rocprofv3 --pmc pass
+# SQ / LDS counters of a command (run on the GPU box through gpurun): one rocprofv3 --pmc pass
 # per counter group, kernel trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots).  usage: pmc_scan.sh <binary> <kernel substring> [args]
 BIN=$1; KERN=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
