@@ -169,7 +169,7 @@ class Pss:
             self.set_N_id_2(n_id_2)
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:  # (module globals are None while the interpreter shuts down)
             lib().lt_pss_free(self._h)
             self._h = None
 
@@ -214,7 +214,7 @@ class Cfo:
         self.nsamples = nsamples
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:  # (module globals are None while the interpreter shuts down)
             lib().lt_cfo_free(self._h)
             self._h = None
 
@@ -244,7 +244,7 @@ class Sync:
             self.set_N_id_2(n_id_2)
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:  # (module globals are None while the interpreter shuts down)
             lib().lt_sync_free(self._h)
             self._h = None
 
@@ -310,7 +310,7 @@ class Batch:
         self._hf_cap = 0
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:  # (module globals are None while the interpreter shuts down)
             lib().lt_batch_free(self._h)
             self._h = None
 

@@ -12,6 +12,8 @@
 // (resolve_window): one workgroup barrier per search.  A lobe too wide for the strips' 64-lag neighbourhoods
 // takes the exact path: the average goes to an LDS mirror and the walk of oracle/lte_oracle.c:300-316 runs on it.
 #pragma once
+#include <cstddef>
+
 #include "lt_scan_kernels.h"
 
 namespace lt {
@@ -202,21 +204,26 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   int buf = 0;
   bool searched = false; // the registers hold the chain's average (a search has run)
   __syncthreads();
-  // the samples of the window searched next are fetched one search ahead (a search is 12 x 2 transforms on one
-  // CU; the memory latency of its 77 KB would otherwise sit in front of every one of them)
-  fft::c32 xpf[16];
-  int64_t pf_pos = INT64_MIN;
-
   // One record: everything the sss side adds (CFO, CP, SSS: lt_kernels.hip, per record) starts out empty.
   auto put_record = [&](int idx, int64_t in_pos, int64_t out_pos, uint32_t flags, int used_peak, int sc, float ps, float pv, float pmax, int tm) {
-    lt_record r;
-    r.in_pos = in_pos; r.out_pos = out_pos; r.channel = channel; r.n_id_2 = n_id_2;
-    r.call_idx = call_base + idx; r.flags = flags; r.peak_pos = used_peak; r.score = sc;
-    r.psr = ps; r.peak_value = pv; r.cfo = 0.f; r.mean_cfo = 0.f;
-    r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
-    r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
-    r.psr_max = pmax; r.timer = tm;
-    recs[idx] = r;
+    // six 16-byte stores, one after the other: a whole lt_record in registers (24 per lane) on top of the strip's
+    // average and the prefetched block is what pushed this kernel into scratch
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 *dst = reinterpret_cast<u4 *>(recs + idx);
+    static_assert(sizeof(lt_record) == 96 && offsetof(lt_record, channel) == 16 && offsetof(lt_record, peak_pos) == 32 &&
+                  offsetof(lt_record, cfo) == 48 && offsetof(lt_record, m0_value) == 64 && offsetof(lt_record, n_id_1) == 80,
+                  "lt_record layout");
+    dst[0] = u4{(uint32_t)in_pos, (uint32_t)(in_pos >> 32), (uint32_t)out_pos, (uint32_t)(out_pos >> 32)};
+    asm volatile("" ::: "memory");
+    dst[1] = u4{(uint32_t)channel, (uint32_t)n_id_2, (uint32_t)(call_base + idx), flags};
+    asm volatile("" ::: "memory");
+    dst[2] = u4{(uint32_t)used_peak, (uint32_t)sc, __float_as_uint(ps), __float_as_uint(pv)};
+    asm volatile("" ::: "memory");
+    dst[3] = u4{0u, 0u, 0u, 0u};                     // cfo, mean_cfo, m_norm_avg, m_ext_avg
+    asm volatile("" ::: "memory");
+    dst[4] = u4{0u, 0u, 0xffffffffu, 0xffffffffu};   // m0_value, m1_value, m0 = m1 = -1
+    asm volatile("" ::: "memory");
+    dst[5] = u4{0xffffffffu, 0xffffffffu, __float_as_uint(pmax), (uint32_t)tm}; // n_id_1 = cell_id = -1
   };
 
   for (;;) {
@@ -255,20 +262,8 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
       // and mask of the search out of the loop and spills them across it)
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      if (pf_pos != wpos) strip_load(cap, wpos, w, ln, xpf); // (first search of the run, or a chain that re-aligned)
       fft::c32 x[16];
-#pragma unroll
-      for (int R = 0; R < 16; ++R) x[R] = xpf[R];
-      // next: the following window of the redo, then the chain's own position; after that a miss leads to
-      // pos + 9600, a tracked chain that keeps its timing searches again track_every + 1 half-frames on
-      int64_t npos;
-      if (redo) npos = (redo_k + 1 < redo_end) ? wpos + (int64_t)redo_stride * kHalfFrame : pos;
-      else npos = pos + (int64_t)kHalfFrame * (is_tracking ? a.track_every + 1 : 1);
-      pf_pos = INT64_MIN;
-      if ((redo && redo_k + 1 < redo_end) || can_call(npos)) {
-        pf_pos = npos;
-        strip_load(cap, npos, w, ln, xpf);
-      }
+      strip_load(cap, wpos, w, ln, x);
       const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo);
       searched = true;
       if (redo) {

@@ -2,7 +2,7 @@
 """BASELINE.json configs 1, 2 and 5 end to end (config 3 / 4 are bench.py).
 
   config 1  cell_search_file contract on lte_frame_6prb_cellid_123 @1.92 Msps, CPU oracle (plumbing)
-  config 2  single channel, 50 PRB fixture @15.36 Msps looped to 1 s: GPU decimator x8 -> chain kernel
+  config 2  single channel, 50 PRB fixture @15.36 Msps looped to 1 s: GPU decimator x8 -> lt_batch_run
             -> host MIB; verify cell_id = 125, nof_prb = 50
   config 5  100 PRB fixture @30.72 Msps + AWGN, SNR -10..+10 dB, threshold 4, N seeded trials per
             point: detection-rate-vs-SNR for the GPU path and for the CPU oracle, trial for trial
@@ -87,7 +87,7 @@ def main():
     cell = events[0][0][1] if events[0] else None
     ms = float(np.median(times))
     res["config2"] = {"input": "lte_frame_50prb_cellid_125 looped x100 @15.36 Msps (15.36 M samples)",
-                      "path": "lt_decim_kernel(x8) -> lt_chain_kernel (3 chains) -> host MIB",
+                      "path": "lt_decim_kernel(x8) -> lt_batch_run (scan rounds, 3 chains) -> host MIB",
                       "cell": cell, "device_ms": round(ms, 3),
                       "msamp_per_s_at_input_rate": round(xin.numel() / ms / 1e3, 1),
                       "ok": bool(cell and cell["cell_id"] == 125 and cell["nof_prb"] == 50
