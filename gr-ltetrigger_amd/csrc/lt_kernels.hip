@@ -582,8 +582,8 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     if (rounds > kMaxRounds) rounds = kMaxRounds;
     hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int) * 2 * (kMaxRounds + 1), stream);
     if (e != hipSuccess) return e;
-    // up to three jobs per channel (one per root when their windows differ)
-    const int grid = (((R.n_channels * 3 + 7) / 8) * 8 + 8) * kScanWgPerJob;
+    // one job per channel; long and short jobs each start on a fresh group of 8 workgroups
+    const int grid = (((R.n_channels + 7) / 8) * 8 + 8) * kScanWgPerJob;
     p.first_round = 1;
     p.round_windows = seg_first;
     p.jobs = jobs2[0];
@@ -612,14 +612,15 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
         const int nj = njj[0] + njj[1];
         int hist[4][4] = {};
         long wsum[4] = {};
-        for (const ScanJob &j : hj) {
-          const int nr = __builtin_popcount(j.roots & 7);
-          hist[nr][j.stride_b > 1 ? 2 : (j.n_a > 0 ? 1 : 0)]++;
-          wsum[nr] += j.n_a + j.n_b;
-        }
+        for (const ScanJob &j : hj)
+          for (int q = 0; q < j.n_seq; ++q) {
+            const int nr = __builtin_popcount(j.seq[q].roots & 7);
+            hist[nr][j.seq[q].stride_b > 1 ? 2 : (j.seq[q].n_a > 0 ? 1 : 0)]++;
+            wsum[nr] += j.seq[q].n_a + j.seq[q].n_b;
+          }
         fprintf(stderr, "round %d: %d jobs;", r, nj);
         for (int nr = 1; nr <= 3; ++nr)
-          fprintf(stderr, "  %d-root: %d plain, %d with prefix, %d strided, %ld windows;", nr, hist[nr][0], hist[nr][1], hist[nr][2], wsum[nr]);
+          fprintf(stderr, "  %d-root sequences: %d plain, %d with prefix, %d strided, %ld windows;", nr, hist[nr][0], hist[nr][1], hist[nr][2], wsum[nr]);
         fprintf(stderr, "\n");
       }
     }

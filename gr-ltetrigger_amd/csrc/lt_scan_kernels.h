@@ -37,19 +37,27 @@
 
 namespace lt {
 
-// One per (channel, window sequence): built by lt_plan_kernel from the chain states, every round anew.
-struct ScanJob {
+// One per channel and round, built by lt_plan_kernel from the chain states: the channel's chains grouped into up to
+// three window sequences.  Chains that will search the same windows (normally all three: idle, on one grid) share
+// a sequence and with it the forward transforms; a chain on windows of its own (it has re-aligned, it tracks)
+// forms a sequence of its own, served by the same workgroups in its own root-wave slot.
+struct ScanSeq {
   int64_t pos_a;      // prefix: windows pos_a + k * stride_a * 9600, k < n_a -- lag metric and average only
   int64_t pos_b;      // the round's windows: pos_b + k * stride_b * 9600, k < n_b
   int32_t stride_a, n_a, stride_b, n_b;
+  int32_t roots;      // bit r: chain (channel, N_id_2 = r) follows this sequence
+  int32_t zero;       // its chains start from an all-zero average
+};
+struct ScanJob {
+  ScanSeq seq[3];     // seq[0] is the longest
   int32_t channel;
-  int32_t roots;      // bit r: chain (channel, N_id_2 = r) is part of the job
-  int32_t zero;       // the job's chains start from an all-zero average
+  int32_t n_seq;
+  int32_t seq_of_root[3]; // -1: the chain is not served this round
   int32_t pad;
 };
-__device__ __forceinline__ int64_t job_window_pos(const ScanJob &j, int k)
+__device__ __forceinline__ int64_t seq_window_pos(const ScanSeq &q, int k)
 {
-  return k < j.n_a ? j.pos_a + (int64_t)k * j.stride_a * kHalfFrame : j.pos_b + (int64_t)(k - j.n_a) * j.stride_b * kHalfFrame;
+  return k < q.n_a ? q.pos_a + (int64_t)k * q.stride_a * kHalfFrame : q.pos_b + (int64_t)(k - q.n_a) * q.stride_b * kHalfFrame;
 }
 
 constexpr int kScanWaves = 12;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   __shared__ v2f SPEC[3][fft::kN];               // filter spectra / 1024, natural order
   __shared__ fft::c32x2 TW1[16 * 64];
   __shared__ fft::c32x2 TW2[16 * 4];
-  __shared__ int sync_ready[kScanGroups], sync_taken[kScanGroups];
+  __shared__ int sync_ready[kScanGroups][3], sync_taken[kScanGroups][3];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroups b, b + 8, b + 16, b + 24 (one XCD under round-robin dispatch) share a job: its strips overlap
@@ -96,15 +104,16 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     if (job_i < 0 || job_i >= n_back) return;
     job_i = a.jobs_cap - 1 - job_i;
   }
-  const ScanJob job = a.jobs[job_i];
-  const int n_w = job.n_a + job.n_b;
-  if (n_w <= 0) return;
+  const ScanJob *jp = a.jobs + job_i; // (read piecewise: a local copy indexed by sequence would live in scratch)
+  const int n_seq = jp->n_seq, channel = jp->channel;
+  if (n_seq <= 0) return;
   // group g = w % 3 owns strip 3 quarter + g; role w / 3: 0 = forward, 1..3 = root 0..2 (the three forward
   // waves land on three different SIMDs)
   const int g = w % kScanGroups, role = w / kScanGroups;
   const int strip = quarter * kScanGroups + g;
   const int root = role - 1;
-  const bool active = role == 0 || ((job.roots >> root) & 1);
+  const int my_seq = role ? jp->seq_of_root[root] : 0;
+  const bool active = role == 0 || my_seq >= 0;
 
   for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw1[i]);
   if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw2[tid]);
@@ -112,62 +121,88 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     const cf32 h = a.tab->pss_spec[i >> 10][i & 1023];
     SPEC[i >> 10][i & 1023] = v2f{h.re, h.im};
   }
-  if (tid < kScanGroups) sync_ready[tid] = sync_taken[tid] = 0;
+  if (tid < kScanGroups * 3) (&sync_ready[0][0])[tid] = (&sync_taken[0][0])[tid] = 0;
   __syncthreads(); // tables in place: the only workgroup barrier
   fft::c32 *e = E + w * fft::kScratchW;
   const fft::c32 *e_fwd = E + g * fft::kScratchW; // the group's forward wave is wave g
 
   Capture cap;
-  cap.iq = a.iq + (int64_t)job.channel * a.ch_stride;
-  cap.hist = a.hist ? a.hist + (int64_t)job.channel * a.hist_stride : nullptr;
+  cap.iq = a.iq + (int64_t)channel * a.ch_stride;
+  cap.hist = a.hist ? a.hist + (int64_t)channel * a.hist_stride : nullptr;
   cap.t0 = a.t0;
   cap.n = a.n;
   cap.hist_len = a.hist ? a.hist_len : 0;
 
   // The two roles run separate loops, so that each gets a register allocation of its own: the forward wave
-  // carries two blocks of samples, a root wave one block and its average.  Hand-over per group through two LDS
-  // counters (no workgroup barrier after the table load: the three groups of a workgroup drift apart, which is
-  // wanted -- every SIMD holds one wave of each group, and waves in different phases of the transform keep
-  // both the vector unit and the LDS busy):
-  //   ready[g] = windows whose first two transform stages sit in the forward wave's exchange area (1 at a time)
-  //   taken[g] = sum over the root waves of the windows they have read from it
-  const int n_roots = __builtin_popcount(job.roots & 7);
+  // carries blocks of samples, a root wave one block and its average.  Hand-over per group and sequence through
+  // two LDS counters (no workgroup barrier after the table load: the three groups of a workgroup drift apart,
+  // which is wanted -- every SIMD holds one wave of each group, and waves in different phases of the transform
+  // keep both the vector unit and the LDS busy):
+  //   ready[g][q] = windows of sequence q whose first two transform stages have sat in the forward wave's exchange area
+  //   taken[g][q] = sum over the sequence's root waves of the windows they have read from it
+  // The exchange area holds one block at a time, whatever its sequence.
 #if LT_SCAN_STAGGER
   for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(LT_SCAN_STAGGER);
 #endif
   if (role == 0) {
+    // sequence 0 (the longest: in general the idle chains' common grid) is fetched two windows ahead; the others
+    // -- a chain or two on windows of their own, a few per round -- are fetched as they come
+    const ScanSeq s0 = jp->seq[0], s1 = jp->seq[1], s2 = jp->seq[2];
+    const int n0 = s0.n_a + s0.n_b;
+    const int n1 = n_seq > 1 ? s1.n_a + s1.n_b : 0;
+    const int n2 = n_seq > 2 ? s2.n_a + s2.n_b : 0;
+    const int r0 = __builtin_popcount(s0.roots & 7);
+    const int r1 = __builtin_popcount(s1.roots & 7);
+    const int r2 = __builtin_popcount(s2.roots & 7);
     fft::c32 x[16];   // the block being transformed
-    fft::c32 xn[16];  // the next two windows' blocks, in flight: a job with one live root, or one whose windows lie
-    fft::c32 xn2[16]; // 9 half-frames apart, turns a window over faster than one memory latency
-    strip_load(cap, job_window_pos(job, 0), strip, lane, x);
-    if (n_w > 1) strip_load(cap, job_window_pos(job, 1), strip, lane, xn);
-    if (n_w > 2) strip_load(cap, job_window_pos(job, 2), strip, lane, xn2);
-    for (int k = 0; k < n_w; ++k) {
-      int ln = lane; // (opaque per iteration: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
-      asm volatile("" : "+v"(ln));
-      // the root waves have taken window k - 1: the exchange area is free
-      while (__hip_atomic_load(&sync_taken[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_roots * k) __builtin_amdgcn_s_sleep(1);
+    fft::c32 xn[16];  // sequence 0: the next two windows' blocks, in flight (a job with one live root turns a
+    fft::c32 xn2[16]; // window over faster than one memory latency)
+    strip_load(cap, seq_window_pos(s0, 0), strip, lane, x);
+    if (n0 > 1) strip_load(cap, seq_window_pos(s0, 1), strip, lane, xn);
+    if (n0 > 2) strip_load(cap, seq_window_pos(s0, 2), strip, lane, xn2);
+    int last_q = -1, last_need = 0; // what sits in the exchange area: its sequence, and the `taken` count that frees it
+    auto hand_over = [&](int q, int k, int n_roots_q, int ln) {
+      // the previous block has been taken by all its root waves: the exchange area is free
+      if (last_q >= 0)
+        while (__hip_atomic_load(&sync_taken[g][last_q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < last_need) __builtin_amdgcn_s_sleep(1);
       LT_LDS_ORDER;
       strip_fft_ab(ln, x, TW1, TW2, e);
       LT_LDS_ORDER;
-      if (lane == 0) __hip_atomic_store(&sync_ready[g], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(&sync_ready[g][q], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      last_q = q;
+      last_need = n_roots_q * (k + 1);
+    };
+    for (int k = 0; k < n0; ++k) {
+      int ln = lane; // (opaque per iteration: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
+      asm volatile("" : "+v"(ln));
+      hand_over(0, k, r0, ln);
+      if (k < n1) {
+        strip_load(cap, seq_window_pos(s1, k), strip, ln, x);
+        hand_over(1, k, r1, ln);
+      }
+      if (k < n2) {
+        strip_load(cap, seq_window_pos(s2, k), strip, ln, x);
+        hand_over(2, k, r2, ln);
+      }
 #pragma unroll
       for (int R = 0; R < 16; ++R) {
         x[R] = xn[R];
         xn[R] = xn2[R];
       }
-      if (k + 3 < n_w) strip_load(cap, job_window_pos(job, k + 3), strip, ln, xn2);
+      if (k + 3 < n0) strip_load(cap, seq_window_pos(s0, k + 3), strip, ln, xn2);
     }
   } else if (active) {
 #ifdef LT_ROOT_PRIO
     __builtin_amdgcn_s_setprio(LT_ROOT_PRIO);
 #endif
+    const ScanSeq sq = jp->seq[my_seq];
+    const int n_w = sq.n_a + sq.n_b;
     fft::c32 x[16]; // spectrum, then lags
     ema_t ema;
-    const int chain = job.channel * 3 + root;
+    const int chain = channel * 3 + root;
     ChainState *st = a.state + chain;
     const int sel = st->ema_sel;
-    if (job.zero) {
+    if (sq.zero) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ema[r] = r < kStripRegs ? 0.f : -FLT_MAX;
     } else {
@@ -183,22 +218,22 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     for (int k = 0; k < n_w; ++k) {
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      while (__hip_atomic_load(&sync_ready[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
       LT_LDS_ORDER;
       LT_PSTAMP(0) // waiting for the forward wave
       fft::fft1024w_stageC<false>(ln, x, e_fwd); // x = the block's spectrum
       LT_LDS_ORDER;
-      if (lane == 0) __hip_atomic_fetch_add(&sync_taken[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_fetch_add(&sync_taken[g][my_seq], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       LT_PSTAMP(1) // last forward stage
 #ifdef LT_SCAN_PROF
       strip_root_update_prof(strip, ln, x, SPEC[root], TW1, TW2, e, ema, pr, tp);
 #else
       strip_root_update(strip, ln, x, SPEC[root], TW1, TW2, e, ema);
 #endif
-      if (k < job.n_a) {
+      if (k < sq.n_a) {
         // prefix window: the chain has been through it already (its record exists); after the last one the
         // average is a state the chain can be restarted from
-        if (k == job.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
+        if (k == sq.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
       } else {
         StripPartial p;
 #ifndef LT_ABL_NO_RESOLVE
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #else
         p.m1 = ema[3]; p.p1 = 0; p.s = ema[5]; p.lb = p.ub = 0; p.a0 = 0.f; p.flags = 0; p.pad = 0;
 #endif
-        if (lane == 0) parts[(int64_t)(k - job.n_a) * kStrips] = p;
+        if (lane == 0) parts[(int64_t)(k - sq.n_a) * kStrips] = p;
       }
       LT_PSTAMP(7) // resolve + store
     }
@@ -241,7 +276,7 @@ struct PlanArgs {
   int call_reach;    // kCallReach (lt_chain_kernel.h)
 };
 
-// the jobs of channel c for the next round
+// the job of channel c for the next round
 __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
 {
   int n[3], stride[3];
@@ -279,29 +314,70 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     if (m > kScanMaxRound - st->pre_n) m = kScanMaxRound - st->pre_n;
     n[r] = m > 0 ? (int)m : 0;
   }
+  // Group the chains into sequences: lead[r] = the first chain of r's group.  (Everything below is written with
+  // constant indices after unrolling: a job assembled in a dynamically indexed local array would live in scratch.)
+  int lead[3], len[3];
+  ScanSeq q[3];
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
-    if (n[r] <= 0) continue;
-    bool leader = true;
-    for (int q = 0; q < r; ++q) leader = leader && !(n[q] > 0 && plain[q] && plain[r] && first[q] == first[r] && stride[q] == stride[r]);
-    if (!leader) continue;
-    const ChainState *st = a.state + c * 3 + r;
-    const bool is_long = st->pre_n + n[r] > a.round_windows / 2;
-    const int j = is_long ? atomicAdd(a.n_jobs, 1) : a.jobs_cap - 1 - atomicAdd(a.n_jobs + 1, 1);
-    ScanJob job;
-    job.pos_a = st->pre_pos; job.stride_a = st->pre_stride; job.n_a = st->pre_n;
-    job.pos_b = first[r]; job.stride_b = stride[r]; job.n_b = n[r];
-    job.channel = c;
-    job.roots = 0;
-    job.zero = st->ema_zero;
-    job.pad = 0;
-    for (int q = r; q < 3; ++q)
-      if (q == r || (n[q] > 0 && plain[q] && plain[r] && first[q] == first[r] && stride[q] == stride[r])) {
-        job.roots |= 1 << q;
-        if (n[q] < job.n_b) job.n_b = n[q];
-        a.state[c * 3 + q].scan_job = j;
-      }
-    a.jobs[j] = job;
+    lead[r] = n[r] > 0 ? r : -1;
+#pragma unroll
+    for (int p = 0; p < r; ++p)
+      if (lead[r] == r && lead[p] == p && plain[p] && plain[r] && first[p] == first[r] && stride[p] == stride[r]) lead[r] = p;
   }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const ChainState *st = a.state + c * 3 + r;
+    q[r].pos_a = st->pre_pos; q[r].stride_a = st->pre_stride; q[r].n_a = st->pre_n;
+    q[r].pos_b = first[r]; q[r].stride_b = stride[r]; q[r].n_b = n[r];
+    q[r].roots = 0;
+    q[r].zero = st->ema_zero;
+#pragma unroll
+    for (int p = r; p < 3; ++p)
+      if (lead[p] == r) {
+        q[r].roots |= 1 << p;
+        if (n[p] < q[r].n_b) q[r].n_b = n[p];
+      }
+    len[r] = lead[r] == r ? q[r].n_a + q[r].n_b : 0;
+  }
+  const int longest = len[0] > len[1] ? (len[0] > len[2] ? len[0] : len[2]) : (len[1] > len[2] ? len[1] : len[2]);
+  if (longest == 0) return;
+  // slot of a leader = the number of leaders that come before it, the longest sequence first (the forward wave
+  // prefetches for it and loops over its windows)
+  int slot[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    slot[r] = 0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      if (p != r && len[p] > 0 && (len[p] > len[r] || (len[p] == len[r] && p < r))) ++slot[r];
+  }
+  const bool is_long = longest > a.round_windows / 2;
+  const int j = is_long ? atomicAdd(a.n_jobs, 1) : a.jobs_cap - 1 - atomicAdd(a.n_jobs + 1, 1);
+  ScanJob *job = a.jobs + j;
+  int n_seq = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (len[r] > 0) {
+      job->seq[slot[r]] = q[r];
+      ++n_seq;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    int sq = -1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      if (lead[r] == p) sq = slot[p];
+    job->seq_of_root[r] = sq;
+    if (sq >= 0) a.state[c * 3 + r].scan_job = j;
+  }
+  for (int i = n_seq; i < 3; ++i) { // (unused slots: read by the scan kernel's forward wave, never followed)
+    ScanSeq z = {};
+    job->seq[i] = z;
+  }
+  job->channel = c;
+  job->n_seq = n_seq;
+  job->pad = 0;
 }
 
 __global__ void lt_plan_kernel(PlanArgs a)
@@ -338,8 +414,8 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
 {
   ChainState *st = a.state + chain;
   if (st->scan_job < 0) return;
-  const ScanJob job = a.jobs[st->scan_job];
   const int channel = chain / 3, n_id_2 = chain % 3;
+  const ScanSeq job = a.jobs[st->scan_job].seq[a.jobs[st->scan_job].seq_of_root[n_id_2]]; // (the chain's window sequence)
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
   // every window's search result, one per lane
   WindowResult wr;

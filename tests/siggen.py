@@ -42,3 +42,39 @@ def scan_channels(base_frames, n_channels, n_samples, snr_db=20.0, cfo=False, se
         iq[c] = s + noise
         expect[c] = cid
     return iq, expect
+
+
+def random_scene(seed, frames_192, names, min_windows=25, max_windows=45, snr_range=(-2.0, 25.0)):
+    """A randomised batch for the record-parity tests (tests/test_gpu_parity.py, tools/stress_parity.py): per
+    channel a random fixture (or none), rotation, SNR between -2 and 25 dB, CFO, a random dropout or level step, a
+    capture length that is not a multiple of anything, an odd channel count; random threshold and tracking
+    parameters.  Returns (iq [n_ch, n] complex64, keyword arguments of the batch)."""
+    rng = np.random.default_rng(seed)
+    n_ch = int(rng.integers(3, 12))
+    n = int(rng.integers(min_windows, max_windows)) * 9600 + int(rng.integers(0, 9600))
+    iq = np.empty((n_ch, n), np.complex64)
+    for c in range(n_ch):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            iq[c] = awgn(rng, n, 1.0)
+            continue
+        frame = frames_192[names[int(rng.integers(0, len(names)))]][19200:38400]
+        p_sig = float(np.mean(np.abs(frame) ** 2))
+        s = loop_to(frame, n, int(rng.integers(0, frame.size)))
+        s = apply_cfo(s, float(rng.uniform(-0.2, 0.2)))
+        snr = float(rng.uniform(*snr_range))
+        x = s + awgn(rng, n, p_sig / 10.0 ** (snr / 10.0))
+        if kind == 2:  # dropout
+            a = int(rng.integers(0, n // 2))
+            m = min(n - a, int(rng.integers(9600, 20 * 9600)))
+            x[a:a + m] = awgn(rng, m, p_sig * 0.05)
+        if kind == 3:  # level step
+            a = int(rng.integers(0, n))
+            x[a:] *= np.float32(rng.uniform(0.05, 20.0))
+        if kind == 4:  # signal disappears
+            a = int(rng.integers(n // 4, n))
+            x[a:] = awgn(rng, n - a, p_sig * 0.05)
+        iq[c] = x
+    kw = dict(psr_threshold=float(rng.choice([2.5, 4.0, 6.0])), track_after=int(rng.choice([2, 8, 16])),
+              track_every=int(rng.choice([0, 3, 8])))
+    return iq, kw

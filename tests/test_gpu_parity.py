@@ -414,35 +414,8 @@ def test_chain_random_scenes(lt, oracle, frames_192, seed):
     """Randomised scenes: per channel a random fixture (or none), rotation, SNR between -2 and 25 dB,
     CFO, a random dropout or level step, a capture length that is not a multiple of anything, an odd
     channel count; random threshold and tracking parameters.  Full record parity, both execution modes."""
-    rng = np.random.default_rng(1000 + seed)
-    n_ch = int(rng.integers(3, 12))
-    n = int(rng.integers(25, 45)) * 9600 + int(rng.integers(0, 9600))
-    names = list(FIXTURES)
-    iq = np.empty((n_ch, n), np.complex64)
-    for c in range(n_ch):
-        kind = int(rng.integers(0, 5))
-        if kind == 0:
-            iq[c] = siggen.awgn(rng, n, 1.0)
-            continue
-        frame = frames_192[names[int(rng.integers(0, len(names)))]][19200:38400]
-        p_sig = float(np.mean(np.abs(frame) ** 2))
-        s = siggen.loop_to(frame, n, int(rng.integers(0, frame.size)))
-        s = siggen.apply_cfo(s, float(rng.uniform(-0.2, 0.2)))
-        snr = float(rng.uniform(-2.0, 25.0))
-        x = s + siggen.awgn(rng, n, p_sig / 10.0 ** (snr / 10.0))
-        if kind == 2:  # dropout
-            a = int(rng.integers(0, n // 2))
-            m = min(n - a, int(rng.integers(9600, 20 * 9600)))
-            x[a:a + m] = siggen.awgn(rng, m, p_sig * 0.05)
-        if kind == 3:  # level step
-            a = int(rng.integers(0, n))
-            x[a:] *= np.float32(rng.uniform(0.05, 20.0))
-        if kind == 4:  # signal disappears
-            a = int(rng.integers(n // 4, n))
-            x[a:] = siggen.awgn(rng, n - a, p_sig * 0.05)
-        iq[c] = x
-    kw = dict(psr_threshold=float(rng.choice([2.5, 4.0, 6.0])), track_after=int(rng.choice([2, 8, 16])),
-              track_every=int(rng.choice([0, 3, 8])))
+    iq, kw = siggen.random_scene(1000 + seed, frames_192, list(FIXTURES))
+    n_ch = iq.shape[0]
     b, got, want = _run_both(lt, oracle, iq, **kw)
     for c in range(3 * n_ch):
         assert_records_match(got[c], want[c], f"seed {seed} {kw} chain {c}")

@@ -49,14 +49,26 @@ int main(int argc, char **argv)
   v2f *diq;
   CK(hipMalloc(&diq, hiq.size() * sizeof(float)));
   CK(hipMemcpy(diq, hiq.data(), hiq.size() * sizeof(float), hipMemcpyHostToDevice));
+  // roots mask, then optionally the number of sequences the roots are spread over (1: all on one grid; 2/3:
+  // root r >= 1 rides in a sequence of its own, offset by 1000 (r) samples)
+  const int roots = argc > 3 ? atoi(argv[3]) : 7;
+  const int n_seq = argc > 4 ? atoi(argv[4]) : 1;
   std::vector<ScanJob> jobs(n_ch);
   for (int c = 0; c < n_ch; ++c) {
-    jobs[c].pos_a = 0; jobs[c].stride_a = 1; jobs[c].n_a = 0;
-    jobs[c].pos_b = 0; jobs[c].stride_b = 1; jobs[c].n_b = n_win;
-    jobs[c].channel = c;
-    jobs[c].roots = argc > 3 ? atoi(argv[3]) : 7;
-    jobs[c].zero = 1;
-    jobs[c].pad = 0;
+    ScanJob &j = jobs[c];
+    memset(&j, 0, sizeof(j));
+    j.channel = c;
+    j.n_seq = n_seq;
+    for (int q = 0; q < n_seq; ++q) {
+      j.seq[q].pos_a = 0; j.seq[q].stride_a = 1; j.seq[q].n_a = 0;
+      j.seq[q].pos_b = 1000 * q; j.seq[q].stride_b = 1; j.seq[q].n_b = n_win;
+      j.seq[q].zero = 1;
+    }
+    for (int r = 0; r < 3; ++r) {
+      const int q = r < n_seq ? r : 0;
+      j.seq_of_root[r] = (roots >> r) & 1 ? q : -1;
+      if ((roots >> r) & 1) j.seq[q].roots |= 1 << r;
+    }
   }
   ScanJob *djobs;
   int *dnj;

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Randomised record parity at volume (run on the GPU box): many seeded scenes from tests/siggen.random_scene
+-- longer captures than the unit tests use (several scan rounds, tracking, re-alignments, lost tracking), low
+and high SNR -- through lt_batch_run in both execution modes and through the CPU oracle; every record field
+compared (integers and the fields downstream of the lag metric bit for bit, the lag-metric fields to 1e-4).
+A scene that differs is saved under --out for replay.  Prints one JSON line.
+
+  python tools/stress_parity.py --scenes 200 --out gpurun_out/stress
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+INT_FIELDS = ["in_pos", "out_pos", "channel", "n_id_2", "call_idx", "flags", "peak_pos", "score",
+              "m0", "m1", "n_id_1", "cell_id", "timer"]
+EXACT_FLOAT_FIELDS = ["cfo", "mean_cfo", "m_norm_avg", "m_ext_avg", "m0_value", "m1_value"]
+METRIC_FIELDS = ["psr", "peak_value", "psr_max"]
+
+
+def first_difference(got, want):
+    if len(got) != len(want):
+        return f"{len(got)} records vs oracle {len(want)}"
+    for f in INT_FIELDS:
+        bad = np.nonzero(got[f] != want[f])[0]
+        if bad.size:
+            return f"{f} at call {int(bad[0])}: {got[f][bad[0]]} vs oracle {want[f][bad[0]]}"
+    for f in EXACT_FLOAT_FIELDS:
+        bad = np.nonzero(got[f].view(np.uint32) != want[f].view(np.uint32))[0]
+        if bad.size:
+            return f"{f} at call {int(bad[0])}: {got[f][bad[0]]!r} vs oracle {want[f][bad[0]]!r}"
+    for f in METRIC_FIELDS:
+        ok = np.isclose(got[f], want[f], rtol=1e-4, atol=0, equal_nan=True)
+        if not ok.all():
+            i = int(np.nonzero(~ok)[0][0])
+            return f"{f} at call {i}: {got[f][i]!r} vs oracle {want[f][i]!r}"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=100)
+    ap.add_argument("--seed0", type=int, default=5000)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--replay", default=None, help="an .npz written by an earlier run")
+    args = ap.parse_args()
+
+    import torch  # noqa: F401  (first: see ltetrigger_amd._binding.lib)
+    import ltetrigger_amd as lt
+    import siggen
+    from conftest import FIXTURES, load_frame
+    from oracle import oracle as O
+
+    frames = {}
+    for name in FIXTURES:
+        x, decim, _ = load_frame(name)
+        frames[name] = O.decimate(np.tile(x, 3), decim)  # as tests/conftest.py::frames_192
+    names = list(FIXTURES)
+
+    def scenes():
+        if args.replay:
+            z = np.load(args.replay, allow_pickle=True)
+            yield -1, z["iq"], dict(z["kw"].item())
+            return
+        for i in range(args.scenes):
+            seed = args.seed0 + i
+            rng = np.random.default_rng(seed)
+            wide = int(rng.integers(0, 3))  # a third each: short, several rounds, long
+            lo, hi = [(25, 45), (60, 140), (130, 260)][wide]
+            snr = [(-6.0, 6.0), (-2.0, 25.0)][int(rng.integers(0, 2))]
+            iq, kw = siggen.random_scene(seed, frames, names, lo, hi, snr)
+            yield seed, iq, kw
+
+    t_start = time.time()
+    bad = []
+    n_records = 0
+    n_samples = 0
+    n_scenes = 0
+    for seed, iq, kw in scenes():
+        want = O.batch_run(iq, nthreads=min(os.cpu_count() or 1, 16), **kw)
+        n_scenes += 1
+        n_samples += iq.size
+        for mode in (1, 0):
+            b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+            b.set_mode(mode)
+            b.run_host(iq)
+            got = b.collect()
+            b.close()
+            for c in range(len(want)):
+                n_records += len(want[c])
+                d = first_difference(got[c], want[c])
+                if d:
+                    bad.append({"seed": seed, "mode": mode, "chain": c, "kw": kw, "what": d})
+                    print(json.dumps(bad[-1]), file=sys.stderr, flush=True)
+                    if args.out and len(bad) <= 3 and not args.replay:
+                        os.makedirs(args.out, exist_ok=True)
+                        np.savez(os.path.join(args.out, f"scene_{seed}.npz"), iq=iq[c // 3:c // 3 + 1], kw=kw)
+                    break
+        if n_scenes % 20 == 0:
+            print(f"{n_scenes} scenes, {len(bad)} differ, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
+    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0],
+           "differing": bad, "seconds": round(time.time() - t_start, 1)}
+    print(json.dumps(res))
+    if args.out:
+        os.makedirs(args.out, exist_ok=True)
+        with open(os.path.join(args.out, "stress_parity.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
