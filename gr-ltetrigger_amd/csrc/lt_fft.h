@@ -9,9 +9,7 @@
 #define LT_HD inline
 #endif
 
-// Scheduling fence (device code only): keeps the compiler from hoisting every LDS twiddle read of a stage
-// above the first multiply, which costs 60 registers and, under the 168-register budget of three waves per
-// SIMD, turns into scratch spills.
+// Scheduling fence (device code only): pins the order "reads issued, butterflies, twiddle products and writes".
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LT_FFT_FENCE __builtin_amdgcn_sched_barrier(0)
 #else
@@ -47,18 +45,25 @@ LT_HD c32 cmulc(c32 a, c32 w)
   const c32 axx = {a.x, a.x}, ayy = {a.y, a.y}, jw = {-w.y, w.x};
   return __builtin_elementwise_fma(axx, w, ayy * jw); // (ax wx - ay wy, ax wy + ay wx)
 }
-// Table twiddles for the full-wave transform carry w and j w side by side, so that a * w and
-// a * conj(w) are 2 packed ops each (the swaps are operand selects, not instructions).
-typedef float c32x2 __attribute__((ext_vector_type(4))); // (wx, wy, -wy, wx)
-template <bool kConjB> LT_HD c32 cmul2(c32 a, c32x2 t)
+// a * w (kConjB: a * conj(w)) for a twiddle read from a table: two packed operations -- the operand swaps, the
+// broadcast of a.x / a.y and the one negation are operand modifiers of v_pk_mul_f32 / v_pk_fma_f32 (written as
+// inline assembly: the compiler turns a negated *variable* operand into v_xor + v_mov and a swap into v_mov's).
+//   p = (ay wy, ay wx);   a w = (ax wx - p.x, ax wy + p.y);   a conj(w) = (ax wx + p.x, -(ax wy) + p.y)
+template <bool kConjB> LT_HD c32 cmulw(c32 a, c32 w)
 {
-  const c32 axx = {a.x, a.x}, ayy = {a.y, a.y};
-  if (kConjB) {
-    const c32 wyx = {t.y, t.x}, wc = {t.w, t.z};            // (wy, wx), (wx, -wy)
-    return __builtin_elementwise_fma(axx, wc, ayy * wyx);   // (ax wx + ay wy, -ax wy + ay wx)
-  }
-  const c32 w = {t.x, t.y}, jw = {t.z, t.w};
-  return __builtin_elementwise_fma(axx, w, ayy * jw);       // (ax wx - ay wy, ax wy + ay wx)
+#if defined(__HIP_DEVICE_COMPILE__)
+  c32 p, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(w));
+  if (kConjB)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(p));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(p));
+  return r;
+#else
+  const float px = a.y * w.y, py = a.y * w.x;
+  if (kConjB) return c32{__builtin_fmaf(a.x, w.x, px), __builtin_fmaf(a.x, -w.y, py)};
+  return c32{__builtin_fmaf(a.x, w.x, -px), __builtin_fmaf(a.x, w.y, py)};
+#endif
 }
 
 // radix-4 butterfly, forward (W4 = -j) or inverse (W4 = +j)
@@ -117,37 +122,78 @@ template <int S, bool kInv> LT_HD void fft16(c32 *v)
 constexpr int kRowA = 68;                  // E1[16][68]
 constexpr int kRowC = 260;                 // E2[4][260]
 constexpr int kScratchW = 16 * kRowA;      // c32 entries of scratch per transform (8704 B; 4 * 260 fits too)
-// tw1[k1 * 64 + l] = W1024^(l k1) (k1 < 16, l < 64);  tw2[t * 4 + c] = W64^(c t) (t < 16, c < 4),
-// both as c32x2 entries (w, j w)
-template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const c32x2 *tw1, c32 *e)
+// tw1[k1 * 64 + l] = W1024^(l k1) (k1 < 16, l < 64);  tw2[t * 4 + c] = W64^(c t) (t < 16, c < 4).
+// A stage's twiddles are read before its butterflies (15 values, 30 registers): a wave's LDS reads return in
+// 100-250 cycles while other waves keep the LDS busy, and read group by group after the butterflies that
+// latency was exposed four times per stage (more than half of the stage's time).
+struct Twiddles { c32 w[15]; };
+LT_HD void stageA_twiddles(int l, const c32 *tw1, Twiddles &t)
+{
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) t.w[k1 - 1] = tw1[k1 * 64 + l];
+}
+LT_HD void stageB_twiddles(int l, const c32 *tw2, Twiddles &t)
+{
+#pragma unroll
+  for (int k = 1; k < 16; ++k) t.w[k - 1] = tw2[k * 4 + (l & 3)];
+}
+template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const Twiddles &t, c32 *e)
 {
   fft16<1, kInv>(v);
   LT_FFT_FENCE;
+  e[l] = v[0];
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
+  for (int k1 = 1; k1 < 16; ++k1) {
 #ifndef LT_ABL_NO_TW
-    if (k1) v[k1] = cmul2<kInv>(v[k1], tw1[k1 * 64 + l]);
+    v[k1] = cmulw<kInv>(v[k1], t.w[k1 - 1]);
+#endif
+    e[k1 * kRowA + l] = v[k1];
+  }
+}
+// kLean: the twiddles are read four at a time after the butterflies instead (8 registers instead of 30, the
+// read latency exposed: for the forward waves of the scan kernel, which hold three blocks of samples and are
+// not the ones the others wait for).
+template <bool kInv, bool kLean = false> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32 *tw2, const c32 *e1, c32 *e2)
+{
+  const int k1 = l >> 2, c = l & 3;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = e1[k1 * kRowA + c + 4 * s];
+  Twiddles t;
+  if (!kLean) stageB_twiddles(l, tw2, t);
+  LT_FFT_FENCE;
+  fft16<1, kInv>(v);
+  LT_FFT_FENCE;
+  e2[c * kRowC + k1] = v[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+#ifndef LT_ABL_NO_TW
+    v[k] = cmulw<kInv>(v[k], kLean ? tw2[k * 4 + c] : t.w[k - 1]);
+#endif
+    e2[c * kRowC + k1 + 16 * k] = v[k];
+    if (kLean && (k & 3) == 3) LT_FFT_FENCE;
+  }
+}
+template <bool kInv> LT_HD void fft1024w_stageA_lean(int l, c32 v[16], const c32 *tw1, c32 *e)
+{
+  fft16<1, kInv>(v);
+  LT_FFT_FENCE;
+  e[l] = v[0];
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) {
+#ifndef LT_ABL_NO_TW
+    v[k1] = cmulw<kInv>(v[k1], tw1[k1 * 64 + l]);
 #endif
     e[k1 * kRowA + l] = v[k1];
     if ((k1 & 3) == 3) LT_FFT_FENCE;
   }
 }
-template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32x2 *tw2, const c32 *e1, c32 *e2)
+// (stage A reading its own twiddles: for callers with nothing to overlap the reads with)
+template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const c32 *tw1, c32 *e)
 {
-  const int k1 = l >> 2, c = l & 3;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) v[s] = e1[k1 * kRowA + c + 4 * s];
+  Twiddles t;
+  stageA_twiddles(l, tw1, t);
   LT_FFT_FENCE;
-  fft16<1, kInv>(v);
-  LT_FFT_FENCE;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-#ifndef LT_ABL_NO_TW
-    if (t) v[t] = cmul2<kInv>(v[t], tw2[t * 4 + c]);
-#endif
-    e2[c * kRowC + k1 + 16 * t] = v[t];
-    if ((t & 3) == 3) LT_FFT_FENCE;
-  }
+  fft1024w_stageA<kInv>(l, v, t, e);
 }
 template <bool kInv> LT_HD void fft1024w_stageC(int l, c32 v[16], const c32 *e2)
 {

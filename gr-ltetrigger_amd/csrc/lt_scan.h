@@ -228,19 +228,16 @@ __device__ __forceinline__ void strip_load(const Capture &c, int64_t w0, int s, 
 {
   const int i0 = strip_sample(s, lane);
   if (w0 >= c.t0 && w0 + kHalfFrame <= c.t0 + c.n) { // window inside the chunk (always, but for the first ones of a run)
-    const v2f *__restrict__ p = c.iq + (w0 - c.t0);
-    if (s > 0 && s < kStrips - 1) {
+    // The window as a buffer resource of 9600 samples: the block's samples in front of the window (negative
+    // offsets, huge as unsigned) and behind it are out of range, and an out-of-range buffer load returns zero --
+    // the window's zero pads without a compare, and one 32-bit offset per load instead of a 64-bit address.
+    const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(c.iq + (w0 - c.t0)), 0, kHalfFrame * (int)sizeof(v2f), 0x00020000);
+    const int off = i0 * (int)sizeof(v2f);
 #pragma unroll
-      for (int R = 0; R < 16; ++R) x[R] = __builtin_nontemporal_load(&p[i0 + 64 * R]);
-    } else { // first / last strip: the block reaches into the window's zero pads
-#pragma unroll
-      for (int R = 0; R < 16; ++R) {
-        const int i = i0 + 64 * R;
-        const bool ok = i >= 0 && i < kHalfFrame;
-        const v2f v = __builtin_nontemporal_load(&p[ok ? i : 0]);
-        v2f z = {0.f, 0.f};
-        x[R] = ok ? v : z;
-      }
+    for (int R = 0; R < 16; ++R) {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(win, off + 64 * R * (int)sizeof(v2f), 0, 2 /* nt */);
+      x[R] = __builtin_bit_cast(v2f, v);
     }
   } else {
     // window across the start of the chunk (the first windows of a lt_batch_push), or across its end: window
@@ -267,8 +264,8 @@ __device__ __forceinline__ void strip_load(const Capture &c, int64_t w0, int s, 
 }
 
 // in-place 1024-point transform of the wave's block (element lane + 64 R in x[R]); e = the wave's exchange area
-template <bool kInv> __device__ __forceinline__ void strip_fft(int lane, fft::c32 (&x)[16], const fft::c32x2 *tw1,
-                                                                const fft::c32x2 *tw2, fft::c32 *e)
+template <bool kInv> __device__ __forceinline__ void strip_fft(int lane, fft::c32 (&x)[16], const fft::c32 *tw1,
+                                                                const fft::c32 *tw2, fft::c32 *e)
 {
   fft::fft1024w_stageA<kInv>(lane, x, tw1, e);
   __builtin_amdgcn_sched_barrier(0);
@@ -278,29 +275,10 @@ template <bool kInv> __device__ __forceinline__ void strip_fft(int lane, fft::c3
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// the first two stages of the forward transform: the block is left in the exchange area e, ready for stage C
-__device__ __forceinline__ void strip_fft_ab(int lane, fft::c32 (&x)[16], const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e)
-{
-  fft::fft1024w_stageA<false>(lane, x, tw1, e);
-  __builtin_amdgcn_sched_barrier(0);
-  fft::fft1024w_stageB<false>(lane, x, tw2, e, e);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// One window of one root of one strip: spectrum of the block (X) times the filter spectrum, back to the lag
-// domain, |.|^2 and the exponential average with its three roundings (srsLTE's three vector passes,
+// |.|^2 of the strip's lags and the exponential average with its three roundings (srsLTE's three vector passes,
 // oracle/lte_oracle.c:289-293).  Lags outside [0, 9726) stay 0.
-__device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f *spec,
-                                                  const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e,
-                                                  ema_t &ema)
+__device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32 (&v)[16], ema_t &ema)
 {
-#pragma unroll
-#ifndef LT_ABL_NO_SPEC
-  for (int R = 0; R < 16; ++R) v[R] = fft::cmul<false>(v[R], spec[lane + 64 * R]);
-#endif
-#ifndef LT_ABL_NO_IFFT
-  strip_fft<true>(lane, v, tw1, tw2, e);
-#endif
   const bool valid0 = !(s == 0 && lane < kStripHalo);
   const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13; // strip 11: lanes below hold lags < 9726
   const bool valid13 = !(s == kStrips - 1 && lane >= end13);
@@ -315,34 +293,54 @@ __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)
   }
 }
 
+// One window of one root of one strip: spectrum of the block (X) times the filter spectrum, back to the lag
+// domain, then the average.  spec = the filter spectrum's bins lane + 64 R, tw = the inverse transform's
+// first-stage twiddles: both read by the caller ahead of time.
+__device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
+                                                  const fft::c32 *tw2, fft::c32 *e, ema_t &ema)
+{
+#ifndef LT_ABL_NO_SPEC
+#pragma unroll
+  for (int R = 0; R < 16; ++R) v[R] = fft::cmulw<false>(v[R], spec[R]);
+#endif
+#ifndef LT_ABL_NO_IFFT
+  fft::fft1024w_stageA<true>(lane, v, tw, e);
+  __builtin_amdgcn_sched_barrier(0);
+  fft::fft1024w_stageB<true>(lane, v, tw2, e, e);
+  __builtin_amdgcn_sched_barrier(0);
+  fft::fft1024w_stageC<true>(lane, v, e);
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  strip_ema_update(s, lane, v, ema);
+}
+__device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f *spec_tab,
+                                                  const fft::c32 *tw1, const fft::c32 *tw2, fft::c32 *e, ema_t &ema)
+{
+  v2f spec[16];
+#pragma unroll
+  for (int R = 0; R < 16; ++R) spec[R] = spec_tab[lane + 64 * R];
+  fft::Twiddles tw;
+  fft::stageA_twiddles(lane, tw1, tw);
+  strip_root_update(s, lane, v, spec, tw, tw2, e, ema);
+}
+
 #ifdef LT_SCAN_PROF
 // diagnostics build: the same with shader-clock stamps between the stages (tools/scan_bench.hip)
-__device__ __forceinline__ void strip_root_update_prof(int s, int lane, fft::c32 (&v)[16], const v2f *spec,
-                                                       const fft::c32x2 *tw1, const fft::c32x2 *tw2, fft::c32 *e,
+__device__ __forceinline__ void strip_root_update_prof(int s, int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
+                                                       const fft::c32 *tw2, fft::c32 *e,
                                                        ema_t &ema, unsigned long long (&pr)[8], unsigned long long &tp)
 {
 #define LT_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-  for (int R = 0; R < 16; ++R) v[R] = fft::cmul<false>(v[R], spec[lane + 64 * R]);
+  for (int R = 0; R < 16; ++R) v[R] = fft::cmulw<false>(v[R], spec[R]);
   LT_PS(2) // filter spectrum
-  fft::fft1024w_stageA<true>(lane, v, tw1, e);
+  fft::fft1024w_stageA<true>(lane, v, tw, e);
   LT_PS(3)
   fft::fft1024w_stageB<true>(lane, v, tw2, e, e);
   LT_PS(4)
   fft::fft1024w_stageC<true>(lane, v, e);
   LT_PS(5)
-  const bool valid0 = !(s == 0 && lane < kStripHalo);
-  const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13;
-  const bool valid13 = !(s == kStrips - 1 && lane >= end13);
-#pragma unroll
-  for (int r = 0; r < kStripRegs; ++r) {
-    const fft::c32 y = v[r + 2];
-    const float met = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
-    float ne = __fadd_rn(__fmul_rn(met, 0.2f), __fmul_rn(ema[r], 1.0f - 0.2f));
-    if (r == 0) ne = valid0 ? ne : 0.f;
-    if (r == kStripRegs - 1) ne = valid13 ? ne : 0.f;
-    ema[r] = ne;
-  }
+  strip_ema_update(s, lane, v, ema);
   LT_PS(6)
 #undef LT_PS
 }

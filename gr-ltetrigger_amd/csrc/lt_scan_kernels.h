@@ -55,6 +55,28 @@ struct ScanJob {
   int32_t seq_of_root[3]; // -1: the chain is not served this round
   int32_t pad;
 };
+// (the job array is written by the kernel before: the compiler reads it with vector loads; its fields are
+// wave-uniform all the same, and everything computed from them -- window positions, buffer resources -- should
+// live in scalar registers)
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ ScanSeq uniform_seq(const ScanSeq &q)
+{
+  ScanSeq u;
+  u.pos_a = uniform_i64(q.pos_a);
+  u.pos_b = uniform_i64(q.pos_b);
+  u.stride_a = uniform_i32(q.stride_a);
+  u.n_a = uniform_i32(q.n_a);
+  u.stride_b = uniform_i32(q.stride_b);
+  u.n_b = uniform_i32(q.n_b);
+  u.roots = uniform_i32(q.roots);
+  u.zero = uniform_i32(q.zero);
+  return u;
+}
 __device__ __forceinline__ int64_t seq_window_pos(const ScanSeq &q, int k)
 {
   return k < q.n_a ? q.pos_a + (int64_t)k * q.stride_a * kHalfFrame : q.pos_b + (int64_t)(k - q.n_a) * q.stride_b * kHalfFrame;
@@ -84,9 +106,11 @@ struct ScanArgs {
 __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 {
   __shared__ v2f E[kScanWaves * fft::kScratchW]; // one exchange area per wave
-  __shared__ v2f SPEC[3][fft::kN];               // filter spectra / 1024, natural order
-  __shared__ fft::c32x2 TW1[16 * 64];
-  __shared__ fft::c32x2 TW2[16 * 4];
+  // a forward wave leaves its blocks (two transform stages done) here for the group's root waves, in turn: while
+  // they read one, it fills the other
+  __shared__ v2f OUT[kScanGroups][2][4 * fft::kRowC];
+  __shared__ fft::c32 TW1[16 * 64];
+  __shared__ fft::c32 TW2[16 * 4];
   __shared__ int sync_ready[kScanGroups][3], sync_taken[kScanGroups][3];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,26 +129,21 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     job_i = a.jobs_cap - 1 - job_i;
   }
   const ScanJob *jp = a.jobs + job_i; // (read piecewise: a local copy indexed by sequence would live in scratch)
-  const int n_seq = jp->n_seq, channel = jp->channel;
+  const int n_seq = uniform_i32(jp->n_seq), channel = uniform_i32(jp->channel);
   if (n_seq <= 0) return;
   // group g = w % 3 owns strip 3 quarter + g; role w / 3: 0 = forward, 1..3 = root 0..2 (the three forward
   // waves land on three different SIMDs)
   const int g = w % kScanGroups, role = w / kScanGroups;
   const int strip = quarter * kScanGroups + g;
   const int root = role - 1;
-  const int my_seq = role ? jp->seq_of_root[root] : 0;
+  const int my_seq = role ? uniform_i32(jp->seq_of_root[root]) : 0;
   const bool active = role == 0 || my_seq >= 0;
 
-  for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw1[i]);
-  if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32x2 *>(a.tab->fft_tw2[tid]);
-  for (int i = tid; i < 3 * fft::kN; i += kScanThreads) {
-    const cf32 h = a.tab->pss_spec[i >> 10][i & 1023];
-    SPEC[i >> 10][i & 1023] = v2f{h.re, h.im};
-  }
+  for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
+  if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
   if (tid < kScanGroups * 3) (&sync_ready[0][0])[tid] = (&sync_taken[0][0])[tid] = 0;
   __syncthreads(); // tables in place: the only workgroup barrier
   fft::c32 *e = E + w * fft::kScratchW;
-  const fft::c32 *e_fwd = E + g * fft::kScratchW; // the group's forward wave is wave g
 
   Capture cap;
   cap.iq = a.iq + (int64_t)channel * a.ch_stride;
@@ -138,65 +157,106 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   // two LDS counters (no workgroup barrier after the table load: the three groups of a workgroup drift apart,
   // which is wanted -- every SIMD holds one wave of each group, and waves in different phases of the transform
   // keep both the vector unit and the LDS busy):
-  //   ready[g][q] = windows of sequence q whose first two transform stages have sat in the forward wave's exchange area
-  //   taken[g][q] = sum over the sequence's root waves of the windows they have read from it
-  // The exchange area holds one block at a time, whatever its sequence.
+  //   ready[g][q] = windows of sequence q whose first two transform stages the forward wave has left in OUT[g]
+  //   taken[g][r] = windows root wave r has read from there (a root wave may be one window ahead of its sequence's others)
+  // Hand-over number h (all sequences of the job counted together, in the forward wave's order) uses OUT[g][h & 1].
 #if LT_SCAN_STAGGER
   for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(LT_SCAN_STAGGER);
 #endif
   if (role == 0) {
-    // sequence 0 (the longest: in general the idle chains' common grid) is fetched two windows ahead; the others
-    // -- a chain or two on windows of their own, a few per round -- are fetched as they come
-    const ScanSeq s0 = jp->seq[0], s1 = jp->seq[1], s2 = jp->seq[2];
+    // Blocks are fetched one hand-over of their kind ahead, each into the registers the block before has just
+    // left (two register sets taking turns for sequence 0, so that no block is ever moved; one for the others'
+    // blocks -- chains on windows of their own, 1 <-> 2 in turn).
+    const ScanSeq s0 = uniform_seq(jp->seq[0]), s1 = uniform_seq(jp->seq[1]), s2 = uniform_seq(jp->seq[2]);
     const int n0 = s0.n_a + s0.n_b;
-    const int n1 = n_seq > 1 ? s1.n_a + s1.n_b : 0;
+    const int n1 = n_seq > 1 ? s1.n_a + s1.n_b : 0; // (n0 >= n1 >= n2)
     const int n2 = n_seq > 2 ? s2.n_a + s2.n_b : 0;
-    const int r0 = __builtin_popcount(s0.roots & 7);
-    const int r1 = __builtin_popcount(s1.roots & 7);
-    const int r2 = __builtin_popcount(s2.roots & 7);
-    fft::c32 x[16];   // the block being transformed
-    fft::c32 xn[16];  // sequence 0: the next two windows' blocks, in flight (a job with one live root turns a
-    fft::c32 xn2[16]; // window over faster than one memory latency)
-    strip_load(cap, seq_window_pos(s0, 0), strip, lane, x);
-    if (n0 > 1) strip_load(cap, seq_window_pos(s0, 1), strip, lane, xn);
-    if (n0 > 2) strip_load(cap, seq_window_pos(s0, 2), strip, lane, xn2);
-    int last_q = -1, last_need = 0; // what sits in the exchange area: its sequence, and the `taken` count that frees it
-    auto hand_over = [&](int q, int k, int n_roots_q, int ln) {
-      // the previous block has been taken by all its root waves: the exchange area is free
-      if (last_q >= 0)
-        while (__hip_atomic_load(&sync_taken[g][last_q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < last_need) __builtin_amdgcn_s_sleep(1);
+    const int r0 = s0.roots & 7, r1 = s1.roots & 7, r2 = s2.roots & 7;
+    fft::c32 xa[16], xb[16]; // sequence 0: even / odd windows
+    fft::c32 xr[16];         // the next block of sequence 1 or 2
+    strip_load(cap, seq_window_pos(s0, 0), strip, lane, xa);
+    if (n0 > 1) strip_load(cap, seq_window_pos(s0, 1), strip, lane, xb);
+    if (n1 > 0) strip_load(cap, seq_window_pos(s1, 0), strip, lane, xr);
+    // what sits in OUT[g][0 / 1]: the root waves it is for and the `taken` count of theirs that frees the buffer
+    int held_roots0 = 0, held_roots1 = 0, held_need0 = 0, held_need1 = 0;
+    int h = 0;
+#ifdef LT_SCAN_PROF
+    unsigned long long pr[8] = {0}, tp = __builtin_amdgcn_s_memtime();
+#define LT_FSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define LT_FSTAMP(i)
+#endif
+    auto hand_over = [&](int q, int k, int roots_q, int ln, fft::c32 (&x)[16]) {
+      LT_FSTAMP(0) // loads issued
+#ifdef LT_SCAN_FWD_LEAN
+      fft::fft1024w_stageA_lean<false>(ln, x, TW1, e);
+#else
+      fft::fft1024w_stageA<false>(ln, x, TW1, e);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      LT_FSTAMP(1) // first stage (and the wait for the block's samples)
+      // the block that used this buffer two hand-overs ago has been taken by all its root waves
+      const int hr = (h & 1) ? held_roots1 : held_roots0, hn = (h & 1) ? held_need1 : held_need0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if ((hr >> r) & 1)
+          while (__hip_atomic_load(&sync_taken[g][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hn) __builtin_amdgcn_s_sleep(1);
+      LT_FSTAMP(2) // waiting for the buffer
       LT_LDS_ORDER;
-      strip_fft_ab(ln, x, TW1, TW2, e);
+#ifdef LT_SCAN_FWD_LEAN
+      fft::fft1024w_stageB<false, true>(ln, x, TW2, e, OUT[g][h & 1]);
+#else
+      fft::fft1024w_stageB<false>(ln, x, TW2, e, OUT[g][h & 1]);
+#endif
       LT_LDS_ORDER;
+      LT_FSTAMP(3) // second stage
       if (lane == 0) __hip_atomic_store(&sync_ready[g][q], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      last_q = q;
-      last_need = n_roots_q * (k + 1);
+      if (h & 1) {
+        held_roots1 = roots_q;
+        held_need1 = k + 1;
+      } else {
+        held_roots0 = roots_q;
+        held_need0 = k + 1;
+      }
+      ++h;
     };
-    for (int k = 0; k < n0; ++k) {
-      int ln = lane; // (opaque per iteration: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
+    auto window = [&](int k, fft::c32 (&x)[16]) {
+      int ln = lane; // (opaque per window: keeps lane-dependent addresses from being hoisted out of the loop and spilled)
       asm volatile("" : "+v"(ln));
-      hand_over(0, k, r0, ln);
+      hand_over(0, k, r0, ln, x);
+      if (k + 2 < n0) strip_load(cap, seq_window_pos(s0, k + 2), strip, ln, x);
       if (k < n1) {
-        strip_load(cap, seq_window_pos(s1, k), strip, ln, x);
-        hand_over(1, k, r1, ln);
+        hand_over(1, k, r1, ln, xr);
+        if (k < n2) strip_load(cap, seq_window_pos(s2, k), strip, ln, xr);
+        else if (k + 1 < n1) strip_load(cap, seq_window_pos(s1, k + 1), strip, ln, xr);
       }
       if (k < n2) {
-        strip_load(cap, seq_window_pos(s2, k), strip, ln, x);
-        hand_over(2, k, r2, ln);
+        hand_over(2, k, r2, ln, xr);
+        if (k + 1 < n1) strip_load(cap, seq_window_pos(s1, k + 1), strip, ln, xr);
       }
-#pragma unroll
-      for (int R = 0; R < 16; ++R) {
-        x[R] = xn[R];
-        xn[R] = xn2[R];
-      }
-      if (k + 3 < n0) strip_load(cap, seq_window_pos(s0, k + 3), strip, ln, xn2);
+    };
+    for (int k = 0; k < n0; k += 2) {
+      window(k, xa);
+      if (k + 1 < n0) window(k + 1, xb);
     }
+#ifdef LT_SCAN_PROF
+    if (a.prof && blockIdx.x == 8 && lane == 0) {
+      for (int i = 0; i < 8; ++i) a.prof[w * 8 + i] = pr[i];
+      unsigned id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+      a.prof[96 + w] = id;
+    }
+#endif
   } else if (active) {
 #ifdef LT_ROOT_PRIO
     __builtin_amdgcn_s_setprio(LT_ROOT_PRIO);
 #endif
-    const ScanSeq sq = jp->seq[my_seq];
+    const ScanSeq sq = uniform_seq(jp->seq[my_seq]);
     const int n_w = sq.n_a + sq.n_b;
+    // hand-over number of this sequence's window k (the forward wave's order: per k, sequence 0, 1, 2 as far as
+    // they reach)
+    const int n1 = n_seq > 1 ? uniform_i32(jp->seq[1].n_a + jp->seq[1].n_b) : 0;
+    const int n2 = n_seq > 2 ? uniform_i32(jp->seq[2].n_a + jp->seq[2].n_b) : 0;
     fft::c32 x[16]; // spectrum, then lags
     ema_t ema;
     const int chain = channel * 3 + root;
@@ -208,6 +268,13 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     } else {
       strip_ema_load(st->avg[sel], strip, lane, ema);
     }
+    // the filter spectrum's 16 bins of this lane stay in registers for the whole job
+    v2f spec[16];
+#pragma unroll
+    for (int R = 0; R < 16; ++R) {
+      const cf32 hh = a.tab->pss_spec[root][lane + 64 * R];
+      spec[R] = v2f{hh.re, hh.im};
+    }
     StripPartial *parts = a.parts + (int64_t)chain * kScanMaxRound * kStrips + strip;
 #ifdef LT_SCAN_PROF
     unsigned long long pr[8] = {0}, tp = __builtin_amdgcn_s_memtime();
@@ -218,17 +285,22 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     for (int k = 0; k < n_w; ++k) {
       int ln = lane;
       asm volatile("" : "+v"(ln));
+      fft::Twiddles tw; // (table reads in flight while the wave waits for the block)
+      fft::stageA_twiddles(ln, TW1, tw);
+      __builtin_amdgcn_sched_barrier(0);
+      const int hk = k + (k < n1 ? k : n1) + (k < n2 ? k : n2) + (my_seq >= 1) + (my_seq >= 2 && k < n1);
+      const fft::c32 *e_fwd = OUT[g][hk & 1];
       while (__hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
       LT_LDS_ORDER;
       LT_PSTAMP(0) // waiting for the forward wave
       fft::fft1024w_stageC<false>(ln, x, e_fwd); // x = the block's spectrum
       LT_LDS_ORDER;
-      if (lane == 0) __hip_atomic_fetch_add(&sync_taken[g][my_seq], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(&sync_taken[g][root], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       LT_PSTAMP(1) // last forward stage
 #ifdef LT_SCAN_PROF
-      strip_root_update_prof(strip, ln, x, SPEC[root], TW1, TW2, e, ema, pr, tp);
+      strip_root_update_prof(strip, ln, x, spec, tw, TW2, e, ema, pr, tp);
 #else
-      strip_root_update(strip, ln, x, SPEC[root], TW1, TW2, e, ema);
+      strip_root_update(strip, ln, x, spec, tw, TW2, e, ema);
 #endif
       if (k < sq.n_a) {
         // prefix window: the chain has been through it already (its record exists); after the last one the
@@ -246,8 +318,12 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
       LT_PSTAMP(7) // resolve + store
     }
 #ifdef LT_SCAN_PROF
-    if (a.prof && blockIdx.x == 8 && w == 7 && lane == 0)
-      for (int i = 0; i < 8; ++i) a.prof[i] = pr[i];
+    if (a.prof && blockIdx.x == 8 && lane == 0) {
+      for (int i = 0; i < 8; ++i) a.prof[w * 8 + i] = pr[i];
+      unsigned id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+      a.prof[96 + w] = id;
+    }
 #endif
     strip_ema_store(st->avg[(sel + 2) % 3], strip, lane, ema);
   }

@@ -60,12 +60,10 @@ void m_sequence(const int taps[], int ntaps, float out[31])
   for (int i = 0; i < 31; ++i) out[i] = (float)(1 - 2 * x[i]);
 }
 
-void pair_entry(float e[4], float re, float im) // (w, j w)
+void pair_entry(float e[2], float re, float im)
 {
   e[0] = re;
   e[1] = im;
-  e[2] = -im;
-  e[3] = re;
 }
 
 double bessel_i0(double x)

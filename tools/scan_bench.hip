@@ -91,8 +91,8 @@ int main(int argc, char **argv)
   a.iq = diq; a.ch_stride = n; a.hist = nullptr; a.hist_stride = 0; a.t0 = 0; a.n = n; a.hist_len = 0;
   a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.tab = dtab; a.jobs_cap = n_ch;
   unsigned long long *dprof;
-  CK(hipMalloc(&dprof, 64));
-  CK(hipMemset(dprof, 0, 64));
+  CK(hipMalloc(&dprof, 8 * 128));
+  CK(hipMemset(dprof, 0, 8 * 128));
   a.prof = dprof;
   const int grid = (((n_ch + 7) / 8) * 8 + 8) * kScanWgPerJob;
   hipEvent_t e0, e1;
@@ -111,15 +111,45 @@ int main(int argc, char **argv)
   }
 #ifdef LT_SCAN_PROF
   {
-    unsigned long long hpr[8];
-    CK(hipMemcpy(hpr, dprof, 64, hipMemcpyDeviceToHost));
-    const char *nm[8] = {"wait fwd", "fwd stage C", "x spec", "inv A", "inv B", "inv C", "mag+ema", "resolve"};
-    unsigned long long tot = 0;
-    for (int i = 0; i < 8; ++i) tot += hpr[i];
-    for (int i = 0; i < 8; ++i) printf("  %-12s %8.1f clocks/window (%4.1f %%)\n", nm[i], (double)hpr[i] / n_win, 100.0 * hpr[i] / tot);
-    printf("  total %.1f clocks/window (s_memtime ticks)\n", (double)tot / n_win);
+    unsigned long long hpr[128];
+    CK(hipMemcpy(hpr, dprof, 8 * 128, hipMemcpyDeviceToHost));
+    const char *nm[8] = {"wait fwd", "fwd C", "x spec", "inv A", "inv B", "inv C", "mag+ema", "resolve"};
+    printf("  clocks per window (s_memtime ticks) of the root waves of workgroup 8:\n  wave simd slot");
+    for (int i = 0; i < 8; ++i) printf(" %8s", nm[i]);
+    printf("    total\n");
+    for (int w = 0; w < 3; ++w) {
+      const unsigned id = (unsigned)hpr[96 + w];
+      printf("  forward wave %d simd %u slot %u: loads+moves %.0f, stage A (+ wait for samples) %.0f, wait for buffer %.0f, stage B %.0f\n", w,
+             (id >> 4) & 3, id & 15, (double)hpr[w * 8] / n_win, (double)hpr[w * 8 + 1] / n_win, (double)hpr[w * 8 + 2] / n_win, (double)hpr[w * 8 + 3] / n_win);
+    }
+    for (int w = 3; w < 12; ++w) {
+      unsigned long long tot = 0;
+      const unsigned id = (unsigned)hpr[96 + w];
+      printf("  %4d %4u %4u", w, (id >> 4) & 3, id & 15);
+      for (int i = 0; i < 8; ++i) {
+        tot += hpr[w * 8 + i];
+        printf(" %8.0f", (double)hpr[w * 8 + i] / n_win);
+      }
+      printf(" %8.0f\n", (double)tot / n_win);
+    }
   }
 #endif
+  {
+    std::vector<StripPartial> all((size_t)n_ch * 3 * kScanMaxRound * kStrips);
+    CK(hipMemcpy(all.data(), dparts, sizeof(StripPartial) * all.size(), hipMemcpyDeviceToHost));
+    unsigned long long sum = 0;
+    for (int c = 0; c < n_ch * 3; ++c)
+      if ((roots >> (c % 3)) & 1)
+        for (int k = 0; k < n_win; ++k)
+          for (int st = 0; st < kStrips; ++st) {
+            const StripPartial &q = all[((size_t)c * kScanMaxRound + k) * kStrips + st];
+            unsigned m, sv;
+            memcpy(&m, &q.m1, 4);
+            memcpy(&sv, &q.s, 4);
+            sum = sum * 1000003ull + m + 3ull * sv + 7ull * (unsigned)q.p1 + 11ull * (unsigned)q.lb + 13ull * (unsigned)q.ub + q.flags;
+          }
+    printf("checksum of the partials (roots %d, %d sequences): %016llx\n", roots, n_seq, sum);
+  }
   std::vector<StripPartial> hp((size_t)kStrips * 4);
   CK(hipMemcpy(hp.data(), dparts, sizeof(StripPartial) * hp.size(), hipMemcpyDeviceToHost));
   for (int i = 0; i < 24; ++i)
