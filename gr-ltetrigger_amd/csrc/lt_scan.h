@@ -61,6 +61,24 @@ __device__ __forceinline__ float wave_prev(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // wave_ror:1
 }
 
+// maximum over the wave, in every lane's hands as a wave-uniform value: four rotations inside the rows of 16, two
+// row broadcasts, one readlane -- the DPP permutation rides on the v_max itself (six vector instructions; the
+// generic wave_max_f of lt_device.h takes twenty-four)
+__device__ __forceinline__ float wave_max_dpp(float f)
+{
+  // (a DPP operand written by the instruction before needs two wait states, and the compiler does not look
+  // inside the block: the leading s_nop covers the instruction that produced f)
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(f));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
+}
+
 // e[r] = average of lag c0 + lane + 64 r (r < 14; e[14], e[15] = -FLT_MAX).  Wave-uniform result in `out` (every
 // lane holds it).  Works on the registers in place -- four of them are patched and put back -- because a masked
 // copy of the tuple would cost 16 moves per window.
@@ -81,7 +99,7 @@ __device__ __forceinline__ void strip_resolve(ema_t &e, int s, int lane, StripPa
   float g[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) g[i] = fmaxf(fmaxf(e[3 * i], e[3 * i + 1]), e[3 * i + 2]); // (e[14] = -FLT_MAX)
-  const float M1 = wave_max_f(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
+  const float M1 = wave_max_dpp(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
   int gi = 0;
 #pragma unroll
   for (int i = 4; i >= 0; --i)
@@ -134,7 +152,7 @@ __device__ __forceinline__ void strip_resolve(ema_t &e, int s, int lane, StripPa
   e[r_b] = (in_lobe && use_b) ? -FLT_MAX : mB;
 #pragma unroll
   for (int i = 0; i < 5; ++i) g[i] = fmaxf(fmaxf(e[3 * i], e[3 * i + 1]), e[3 * i + 2]);
-  const float S = wave_max_f(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
+  const float S = wave_max_dpp(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
   e[r_p] = mA;
   e[r_b] = mB;
   e[0] = full0;
@@ -282,15 +300,22 @@ __device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32
   const bool valid0 = !(s == 0 && lane < kStripHalo);
   const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13; // strip 11: lanes below hold lags < 9726
   const bool valid13 = !(s == kStrips - 1 && lane >= end13);
+  // (written on whole vectors so that the products and sums pair up in place, in the tuple's own registers)
+  ema_t met;
 #pragma unroll
-  for (int r = 0; r < kStripRegs; ++r) {
-    const fft::c32 y = v[r + 2];
-    const float met = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
-    float ne = __fadd_rn(__fmul_rn(met, 0.2f), __fmul_rn(ema[r], 1.0f - 0.2f));
-    if (r == 0) ne = valid0 ? ne : 0.f;
-    if (r == kStripRegs - 1) ne = valid13 ? ne : 0.f;
-    ema[r] = ne;
+  for (int r = 0; r < 16; ++r) {
+    const fft::c32 y = v[r < kStripRegs ? r + 2 : 0];
+    const fft::c32 sq = y * y;
+    float m; // (as assembly: left to itself the compiler shuffles two lags' squares into pairs to add them packed)
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(sq.x), "v"(sq.y));
+    met[r] = m;
   }
+  ema_t ne = met * 0.2f + ema * (1.0f - 0.2f); // (no contraction: the build has -ffp-contract=off)
+  ne[0] = valid0 ? ne[0] : 0.f;
+  ne[kStripRegs - 1] = valid13 ? ne[kStripRegs - 1] : 0.f;
+  ne[14] = -FLT_MAX;
+  ne[15] = -FLT_MAX;
+  ema = ne;
 }
 
 // One window of one root of one strip: spectrum of the block (X) times the filter spectrum, back to the lag

@@ -12,7 +12,7 @@
 
 struct WaveRep { unsigned long long ticks; unsigned hw_id; unsigned pad; };
 
-template <int kOp> __global__ void k_ports(float *out, int iters, const int *weight, WaveRep *rep)
+template <int kOp> __global__ void k_ports(float *out, int iters, const int *weight, WaveRep *rep, int prio_from = 99)
 {
   extern __shared__ float lds_pad[]; // (sized to keep one workgroup per CU)
   float a[8];
@@ -22,6 +22,7 @@ template <int kOp> __global__ void k_ports(float *out, int iters, const int *wei
   const float b = 1.0000001f, c = 1e-9f;
   const int w = threadIdx.x >> 6;
   const int n = iters * weight[w];
+  if (w >= prio_from) __builtin_amdgcn_s_setprio(2);
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < n; ++it) {
@@ -50,7 +51,7 @@ template <int kOp> __global__ void k_ports(float *out, int iters, const int *wei
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-template <int kOp> static int run(const char *name, int waves, const std::vector<int> &weight, float *out, int *dw, WaveRep *drep)
+template <int kOp> static int run(const char *name, int waves, const std::vector<int> &weight, float *out, int *dw, WaveRep *drep, int prio_from = 99)
 {
   const int iters = 2000;
   CK(hipMemcpy(dw, weight.data(), sizeof(int) * waves, hipMemcpyHostToDevice));
@@ -58,9 +59,9 @@ template <int kOp> static int run(const char *name, int waves, const std::vector
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  k_ports<kOp><<<256, waves * 64, 100 * 1024>>>(out, 10, dw, drep);
+  k_ports<kOp><<<256, waves * 64, 100 * 1024>>>(out, 10, dw, drep, prio_from);
   CK(hipEventRecord(e0));
-  k_ports<kOp><<<256, waves * 64, 100 * 1024>>>(out, iters, dw, drep);
+  k_ports<kOp><<<256, waves * 64, 100 * 1024>>>(out, iters, dw, drep, prio_from);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms;
@@ -70,7 +71,7 @@ template <int kOp> static int run(const char *name, int waves, const std::vector
   printf("%s, %d waves per workgroup, one workgroup per CU: %.3f ms\n", name, waves, ms);
   for (int w = 0; w < waves; ++w) {
     const unsigned id = rep[w].hw_id;
-    const double per = (double)rep[w].ticks / ((double)iters * weight[w] * 32.0);
+    const double per = weight[w] ? (double)rep[w].ticks / ((double)iters * weight[w] * 32.0) : 0.0;
     printf("  wave %2d  weight %d  simd %u  slot %2u  cu %2u  ticks %9llu  (%.2f ticks per instruction)\n", w, weight[w], (id >> 4) & 3,
            id & 15, (id >> 8) & 15, rep[w].ticks, per);
   }
@@ -98,6 +99,13 @@ int main()
     // light waves last
     std::vector<int> scan2 = {3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1};
     if (run<0>("v_add_f32, waves 9..11 a third of the work", 12, scan2, out, dw, drep)) return 1;
+    // which waves does a SIMD's third wave compete with?  (weight 0 = the wave does nothing)
+    std::vector<int> no1 = {1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1};
+    if (run<0>("v_add_f32, second wave of every SIMD idle", 12, no1, out, dw, drep)) return 1;
+    std::vector<int> no0 = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1};
+    if (run<0>("v_add_f32, first wave of every SIMD idle", 12, no0, out, dw, drep)) return 1;
+    // does s_setprio move the penalty?  the third wave of every SIMD at raised priority
+    if (run<0>("v_add_f32, equal work, waves 8..11 at s_setprio 2", 12, one, out, dw, drep, 8)) return 1;
   }
   return 0;
 }
