@@ -157,7 +157,7 @@ struct lt_batch {
   int64_t hist_cap = 0;
   int64_t t0 = 0;            // absolute stream position of the next chunk
   int mode = 1;              // 0 per-chain kernel only, 1 grid scan + per-chain kernel
-  int seg_first = 2, seg_len = 64;
+  int seg_first = 2, seg_len = 0;
   bool pending_reset = false; // lt_batch_reset: applied on the stream of the next run, in front of it
   // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, scan done, per-chain kernel done, end
   static constexpr int kPhaseRing = 8;
@@ -777,8 +777,8 @@ int lt_batch_get_mode(lt_batch *b) { return b ? b->mode : fail(LT_ERROR_INVALID_
 
 int lt_batch_set_scan_segments(lt_batch *b, int first, int later)
 {
-  if (!b || first < 1 || later < 1 || first > lt::scan_max_round() || later > lt::scan_max_round())
-    return fail(LT_ERROR_INVALID_INPUTS, "windows per scan round must be in [1, %d]", lt::scan_max_round());
+  if (!b || first < 1 || later < 0 || first > lt::scan_max_round() || later > lt::scan_max_round())
+    return fail(LT_ERROR_INVALID_INPUTS, "windows per scan round must be in [1, %d] (later: 0 = automatic)", lt::scan_max_round());
   b->seg_first = first;
   b->seg_len = later;
   return LT_OK;

@@ -575,8 +575,13 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     q.rec_count = R.rec_count; q.t1 = t1; q.flush = R.flush; q.call_reach = kCallReach; q.psr_threshold = R.psr_threshold;
     q.track_after = R.track_after; q.track_every = R.track_every;
     const int seg_first = R.seg_first < 1 ? 1 : R.seg_first > kScanMaxRound ? kScanMaxRound : R.seg_first;
-    const int seg_len = R.seg_len < 1 ? 1 : R.seg_len > kScanMaxRound ? kScanMaxRound : R.seg_len;
     const int64_t windows = (R.n + R.hist_len) / kHalfFrame + 1;
+    int seg_len = R.seg_len > kScanMaxRound ? kScanMaxRound : R.seg_len;
+    if (seg_len < 1) { // as few rounds as the windows need, all of one length
+      const int64_t rest = windows > seg_first ? windows - seg_first : 1;
+      const int64_t n_rounds = (rest + kScanMaxRound - 1) / kScanMaxRound;
+      seg_len = (int)((rest + n_rounds - 1) / n_rounds);
+    }
     int rounds = 1;
     if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
     if (rounds > kMaxRounds) rounds = kMaxRounds;
@@ -616,8 +621,14 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
           for (int q = 0; q < j.n_seq; ++q) {
             const int nr = __builtin_popcount(j.seq[q].roots & 7);
             hist[nr][j.seq[q].stride_b > 1 ? 2 : (j.seq[q].n_a > 0 ? 1 : 0)]++;
-            wsum[nr] += j.seq[q].n_a + j.seq[q].n_b;
+            wsum[nr] += j.seq[q].n_a + j.seq[q].n_b + j.seq[q].n_c;
           }
+        if (nj <= 4)
+          for (const ScanJob &j : hj)
+            for (int q = 0; q < j.n_seq; ++q)
+              fprintf(stderr, "  round %d channel %d seq %d roots %d zero %d: A %lld x%d n%d | B %lld x%d n%d | C %lld x%d n%d\n", r, j.channel, q,
+                      j.seq[q].roots, j.seq[q].zero, (long long)j.seq[q].pos_a, j.seq[q].stride_a, j.seq[q].n_a, (long long)j.seq[q].pos_b,
+                      j.seq[q].stride_b, j.seq[q].n_b, (long long)j.seq[q].pos_c, j.seq[q].stride_c, j.seq[q].n_c);
         fprintf(stderr, "round %d: %d jobs;", r, nj);
         for (int nr = 1; nr <= 3; ++nr)
           fprintf(stderr, "  %d-root sequences: %d plain, %d with prefix, %d strided, %ld windows;", nr, hist[nr][0], hist[nr][1], hist[nr][2], wsum[nr]);

@@ -39,7 +39,7 @@ struct RunLaunch {
   int *n_jobs = nullptr;      // device, 2 x (scan_max_rounds() + 1) counters
   void *parts = nullptr;      // device, scan_parts_bytes_per_chain() per chain
   int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
-  int seg_len = 64;           // windows per job in the later rounds (<= scan_max_round())
+  int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
   int extra_rounds = 2;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel

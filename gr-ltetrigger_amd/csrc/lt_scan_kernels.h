@@ -44,7 +44,10 @@ namespace lt {
 struct ScanSeq {
   int64_t pos_a;      // prefix: windows pos_a + k * stride_a * 9600, k < n_a -- lag metric and average only
   int64_t pos_b;      // the round's windows: pos_b + k * stride_b * 9600, k < n_b
-  int32_t stride_a, n_a, stride_b, n_b;
+  int64_t pos_c;      // ... and, for a chain about to start tracking, pos_c + k * stride_c * 9600, k < n_c: the
+                      // searches of the tracked chain, its average cleared in front of the first one
+                      // (srslte_pss_reset where tracking starts, lib/pss_impl.cc:119-126)
+  int32_t stride_a, n_a, stride_b, n_b, stride_c, n_c;
   int32_t roots;      // bit r: chain (channel, N_id_2 = r) follows this sequence
   int32_t zero;       // its chains start from an all-zero average
 };
@@ -69,6 +72,9 @@ __device__ __forceinline__ ScanSeq uniform_seq(const ScanSeq &q)
   ScanSeq u;
   u.pos_a = uniform_i64(q.pos_a);
   u.pos_b = uniform_i64(q.pos_b);
+  u.pos_c = uniform_i64(q.pos_c);
+  u.stride_c = uniform_i32(q.stride_c);
+  u.n_c = uniform_i32(q.n_c);
   u.stride_a = uniform_i32(q.stride_a);
   u.n_a = uniform_i32(q.n_a);
   u.stride_b = uniform_i32(q.stride_b);
@@ -77,16 +83,20 @@ __device__ __forceinline__ ScanSeq uniform_seq(const ScanSeq &q)
   u.zero = uniform_i32(q.zero);
   return u;
 }
+__device__ __forceinline__ int seq_windows(const ScanSeq &q) { return q.n_a + q.n_b + q.n_c; }
 __device__ __forceinline__ int64_t seq_window_pos(const ScanSeq &q, int k)
 {
-  return k < q.n_a ? q.pos_a + (int64_t)k * q.stride_a * kHalfFrame : q.pos_b + (int64_t)(k - q.n_a) * q.stride_b * kHalfFrame;
+  if (k < q.n_a) return q.pos_a + (int64_t)k * q.stride_a * kHalfFrame;
+  k -= q.n_a;
+  if (k < q.n_b) return q.pos_b + (int64_t)k * q.stride_b * kHalfFrame;
+  return q.pos_c + (int64_t)(k - q.n_b) * q.stride_c * kHalfFrame;
 }
 
 constexpr int kScanWaves = 12;
 constexpr int kScanThreads = 64 * kScanWaves;
 constexpr int kScanGroups = 3;              // strips per workgroup
 constexpr int kScanWgPerJob = kStrips / kScanGroups;
-constexpr int kScanMaxRound = 64;           // windows per job and round at most (one resolver lane each)
+constexpr int kScanMaxRound = 128;           // windows per job and round at most (one resolver lane each)
 
 struct ScanArgs {
   const v2f *iq;       // [n_channels][ch_stride]
@@ -168,9 +178,9 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     // left (two register sets taking turns for sequence 0, so that no block is ever moved; one for the others'
     // blocks -- chains on windows of their own, 1 <-> 2 in turn).
     const ScanSeq s0 = uniform_seq(jp->seq[0]), s1 = uniform_seq(jp->seq[1]), s2 = uniform_seq(jp->seq[2]);
-    const int n0 = s0.n_a + s0.n_b;
-    const int n1 = n_seq > 1 ? s1.n_a + s1.n_b : 0; // (n0 >= n1 >= n2)
-    const int n2 = n_seq > 2 ? s2.n_a + s2.n_b : 0;
+    const int n0 = seq_windows(s0);
+    const int n1 = n_seq > 1 ? seq_windows(s1) : 0; // (n0 >= n1 >= n2)
+    const int n2 = n_seq > 2 ? seq_windows(s2) : 0;
     const int r0 = s0.roots & 7, r1 = s1.roots & 7, r2 = s2.roots & 7;
     fft::c32 xa[16], xb[16]; // sequence 0: even / odd windows
     fft::c32 xr[16];         // the next block of sequence 1 or 2
@@ -252,11 +262,11 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     __builtin_amdgcn_s_setprio(LT_ROOT_PRIO);
 #endif
     const ScanSeq sq = uniform_seq(jp->seq[my_seq]);
-    const int n_w = sq.n_a + sq.n_b;
+    const int n_w = seq_windows(sq);
     // hand-over number of this sequence's window k (the forward wave's order: per k, sequence 0, 1, 2 as far as
     // they reach)
-    const int n1 = n_seq > 1 ? uniform_i32(jp->seq[1].n_a + jp->seq[1].n_b) : 0;
-    const int n2 = n_seq > 2 ? uniform_i32(jp->seq[2].n_a + jp->seq[2].n_b) : 0;
+    const int n1 = n_seq > 1 ? uniform_i32(jp->seq[1].n_a + jp->seq[1].n_b + jp->seq[1].n_c) : 0;
+    const int n2 = n_seq > 2 ? uniform_i32(jp->seq[2].n_a + jp->seq[2].n_b + jp->seq[2].n_c) : 0;
     fft::c32 x[16]; // spectrum, then lags
     ema_t ema;
     const int chain = channel * 3 + root;
@@ -297,6 +307,10 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
       LT_LDS_ORDER;
       if (lane == 0) __hip_atomic_store(&sync_taken[g][root], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       LT_PSTAMP(1) // last forward stage
+      if (k == sq.n_a + sq.n_b && sq.n_c > 0) { // tracking starts here: srslte_pss_reset
+#pragma unroll
+        for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+      }
 #ifdef LT_SCAN_PROF
       strip_root_update_prof(strip, ln, x, spec, tw, TW2, e, ema, pr, tp);
 #else
@@ -355,9 +369,9 @@ struct PlanArgs {
 // the job of channel c for the next round
 __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
 {
-  int n[3], stride[3];
-  int64_t first[3];
-  bool plain[3]; // the average is avg[ema_sel] as it stands
+  int n[3], stride[3], n_c[3];
+  int64_t first[3], pos_c[3];
+  bool plain[3]; // the average is avg[ema_sel] as it stands, and the windows end with the round
   const int64_t limit = a.t1 - (a.flush ? kHalfFrame : a.call_reach); // last position a call may start at
   for (int r = 0; r < 3; ++r) {
     ChainState *st = a.state + c * 3 + r;
@@ -368,6 +382,8 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     }
     st->scan_job = -1;
     n[r] = 0;
+    n_c[r] = 0;
+    pos_c[r] = 0;
     stride[r] = st->is_tracking ? a.track_every + 1 : 1;
     // the calls before the next search emit without searching: timer of them (lib/pss_impl.cc:170-172)
     first[r] = st->pos + (st->is_tracking ? (int64_t)st->timer * kHalfFrame : 0);
@@ -386,9 +402,33 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     // lib/pss_impl.cc:134-151) gets two windows; one whose average has just been reset tends to fire at once and
     // to start tracking track_after windows later, so it gets no more than that.
     if (!st->is_tracking && st->pre_n > 0 && m > 2) m = 2;
-    if (!st->is_tracking && st->ema_zero && m > a.track_after + 1) m = a.track_after + 1;
+    // ... and, if it does, to start tracking track_after windows later: no more than those here.  (ema_zero is set
+    // by a reset only: a stream starts from avg[0] = zeros, not from the flag.)
+    const bool after_reset = !st->is_tracking && st->score == 0 && st->ema_zero;
+    if (after_reset && m > a.track_after) m = a.track_after;
     if (m > kScanMaxRound - st->pre_n) m = kScanMaxRound - st->pre_n;
     n[r] = m > 0 ? (int)m : 0;
+    // A chain that is building its score on windows of its own keeps its position while it hits (the peak sits
+    // where the last hit put it), starts tracking with the hit that takes the score to track_after, clears its
+    // average there and searches every (track_every + 1)-th half-frame from then on: those searches ride along
+    // in the same round.  (If a window misses, the resolver stops following the sequence there.)
+    const int hits = a.track_after - st->score;
+    if (!st->is_tracking && (st->score > 0 || after_reset) && st->pre_n == 0 && n[r] == hits && hits > 0) {
+      const int sc = a.track_every + 1;
+      const int64_t pc = first[r] + (int64_t)(hits - 1) * kHalfFrame + (int64_t)sc * kHalfFrame;
+      if (pc <= limit) {
+        int64_t mc = (limit - pc) / ((int64_t)sc * kHalfFrame) + 1;
+        const int64_t room_c = (a.rec_cap - a.rec_count[c * 3 + r] - hits - a.track_every) / sc;
+        if (mc > room_c) mc = room_c;
+        if (mc > a.round_windows - n[r]) mc = a.round_windows - n[r];
+        if (mc > kScanMaxRound - n[r]) mc = kScanMaxRound - n[r];
+        if (mc > 0) {
+          n_c[r] = (int)mc;
+          pos_c[r] = pc;
+          plain[r] = false;
+        }
+      }
+    }
   }
   // Group the chains into sequences: lead[r] = the first chain of r's group.  (Everything below is written with
   // constant indices after unrolling: a job assembled in a dynamically indexed local array would live in scratch.)
@@ -406,6 +446,7 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     const ChainState *st = a.state + c * 3 + r;
     q[r].pos_a = st->pre_pos; q[r].stride_a = st->pre_stride; q[r].n_a = st->pre_n;
     q[r].pos_b = first[r]; q[r].stride_b = stride[r]; q[r].n_b = n[r];
+    q[r].pos_c = pos_c[r]; q[r].stride_c = a.track_every + 1; q[r].n_c = n_c[r];
     q[r].roots = 0;
     q[r].zero = st->ema_zero;
 #pragma unroll
@@ -414,7 +455,7 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
         q[r].roots |= 1 << p;
         if (n[p] < q[r].n_b) q[r].n_b = n[p];
       }
-    len[r] = lead[r] == r ? q[r].n_a + q[r].n_b : 0;
+    len[r] = lead[r] == r ? q[r].n_a + q[r].n_b + q[r].n_c : 0;
   }
   const int longest = len[0] > len[1] ? (len[0] > len[2] ? len[0] : len[2]) : (len[1] > len[2] ? len[1] : len[2]);
   if (longest == 0) return;
@@ -493,11 +534,6 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
   const int channel = chain / 3, n_id_2 = chain % 3;
   const ScanSeq job = a.jobs[st->scan_job].seq[a.jobs[st->scan_job].seq_of_root[n_id_2]]; // (the chain's window sequence)
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
-  // every window's search result, one per lane
-  WindowResult wr;
-  wr.peak_pos = 0; wr.peak_value = 0.f; wr.psr = 0.f; wr.exact = true;
-  if (lane < job.n_b) wr = resolve_window(a.parts + ((int64_t)chain * kScanMaxRound + lane) * kStrips);
-
   int64_t pos = st->pos;
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer, tracking_lost = st->tracking_lost;
   int peak_pos = st->peak_pos;
@@ -548,118 +584,140 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
   int used = 0;          // windows of the job whose search has been executed
   bool ema_reset = false, stop_run = false, need_chain = false;
   run_timer_calls();
-  // ---- an idle chain (lib/pss_impl.cc:134-135: a miss with score 0 changes nothing but d_psr, the ring and the
-  // position): all the misses up to the first window that fires, one lane each
-  int k0 = 0;
-  if (!is_tracking && score == 0 && !tracking_lost && job.stride_b == 1 && pos == job.pos_b) {
-    int fit = job.n_b;
-    if (pos > limit) fit = 0;
-    else if ((limit - pos) / kHalfFrame + 1 < fit) fit = (int)((limit - pos) / kHalfFrame + 1);
-    if (a.rec_cap - nrec < fit) fit = a.rec_cap - nrec;
-    const bool valid = lane < fit;
-    const bool fire = valid && (!wr.exact || wr.psr > a.psr_threshold);
-    const unsigned long long fm = __ballot(fire);
-    const int n_miss = fm ? __builtin_ctzll(fm) : fit;
-    if (n_miss > 0) {
-      const bool miss = lane < n_miss;
-      float pm = miss ? wr.psr : -FLT_MAX; // d_psr_max as an inclusive prefix maximum
-      if (!(pm == pm)) pm = -FLT_MAX;      // a NaN never raises it
+  // The round's windows, 64 at a time: every window's search result, one per lane, then the calls in order.
+  const int n_bc = job.n_b + job.n_c;
+  int track_k = -1; // the window whose hit started tracking (and cleared the average)
+  for (int blk = 0; blk < n_bc; blk += 64) {
+    const int nb = n_bc - blk < 64 ? n_bc - blk : 64;
+    WindowResult wr;
+    wr.peak_pos = 0; wr.peak_value = 0.f; wr.psr = 0.f; wr.exact = true;
+    if (lane < nb) wr = resolve_window(a.parts + ((int64_t)chain * kScanMaxRound + blk + lane) * kStrips);
+    // ---- an idle chain (lib/pss_impl.cc:134-135: a miss with score 0 changes nothing but d_psr, the ring and the
+    // position): all the misses up to the first window that fires, one lane each
+    int k0 = 0;
+    if (!ema_reset && !is_tracking && score == 0 && !tracking_lost && job.stride_b == 1 && blk < job.n_b && pos == job.pos_b + (int64_t)blk * kHalfFrame) {
+      int fit = job.n_b - blk < nb ? job.n_b - blk : nb;
+      if (pos > limit) fit = 0;
+      else if ((limit - pos) / kHalfFrame + 1 < fit) fit = (int)((limit - pos) / kHalfFrame + 1);
+      if (a.rec_cap - nrec < fit) fit = a.rec_cap - nrec;
+      const bool valid = lane < fit;
+      const bool fire = valid && (!wr.exact || wr.psr > a.psr_threshold);
+      const unsigned long long fm = __ballot(fire);
+      const int n_miss = fm ? __builtin_ctzll(fm) : fit;
+      if (n_miss > 0) {
+        const bool miss = lane < n_miss;
+        float pm = miss ? wr.psr : -FLT_MAX; // d_psr_max as an inclusive prefix maximum
+        if (!(pm == pm)) pm = -FLT_MAX;      // a NaN never raises it
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(pm, d);
-        if (lane >= d) pm = fmaxf(pm, o);
-      }
-      const float my_max = fmaxf(psr_max, pm);
-      if (miss) {
-        lt_record r;
-        r.in_pos = pos + (int64_t)lane * kHalfFrame; r.out_pos = -1; r.channel = channel; r.n_id_2 = n_id_2;
-        r.call_idx = call_base + nrec + lane; r.flags = LT_F_SEARCHED; r.peak_pos = wr.peak_pos; r.score = 0;
-        r.psr = wr.psr; r.peak_value = wr.peak_value; r.cfo = 0.f; r.mean_cfo = 0.f;
-        r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
-        r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
-        r.psr_max = my_max; r.timer = a.track_every;
-        recs[nrec + lane] = r;
-        st->psr_data[(psr_i + (uint32_t)lane) % kMovingAvgSz] = wr.psr; // d_psr_data ring (lib/pss_impl.cc:166)
-      }
-      psr_max = __shfl(my_max, n_miss - 1);
-      psr = __shfl(wr.psr, n_miss - 1);
-      peak_pos = __shfl(wr.peak_pos, n_miss - 1);
-      timer = a.track_every;
-      psr_i += (uint32_t)n_miss;
-      nrec += n_miss;
-      pos += (int64_t)n_miss * kHalfFrame;
-      used = n_miss;
-      k0 = n_miss;
-    }
-  }
-  for (int k = k0; k < job.n_b; ++k) {
-    const int64_t pk = job.pos_b + (int64_t)k * job.stride_b * kHalfFrame;
-    if (ema_reset || pos != pk || (is_tracking ? a.track_every + 1 : 1) != job.stride_b) break; // off the job's windows
-    if (is_tracking && timer != 0) break; // (the calls before the search did not all fit)
-    if (!(pos <= limit && nrec < a.rec_cap)) {
-      stop_run = true;
-      break;
-    }
-    if (!__shfl((int)wr.exact, k)) { // a lobe the strips could not close: the per-chain kernel searches this window
-      need_chain = true;
-      break;
-    }
-    used = k + 1;
-    // ---- lib/pss_impl.cc:163-172: the search
-    uint32_t flags = LT_F_SEARCHED;
-    timer = a.track_every;
-    peak_pos = __shfl(wr.peak_pos, k);
-    psr = __shfl(wr.psr, k);
-    const float peak_value = __shfl(wr.peak_value, k);
-    if (lane == 0) st->psr_data[psr_i % kMovingAvgSz] = psr;
-    psr_i++;
-    const int used_peak_pos = peak_pos;
-    // ---- score, lib/pss_impl.cc:174-182 (incr_score :111-127, reset_score :129-152)
-    const bool over = psr > a.psr_threshold;
-    if (over) {
-      if (!(is_tracking && score == a.track_after)) {
-        score++;
-        if (!is_tracking && score == a.track_after) {
-          is_tracking = 1;
-          ema_reset = true; // srslte_pss_reset
+        for (int d = 1; d < 64; d <<= 1) {
+          const float o = __shfl_up(pm, d);
+          if (lane >= d) pm = fmaxf(pm, o);
         }
+        const float my_max = fmaxf(psr_max, pm);
+        if (miss) {
+          lt_record r;
+          r.in_pos = pos + (int64_t)lane * kHalfFrame; r.out_pos = -1; r.channel = channel; r.n_id_2 = n_id_2;
+          r.call_idx = call_base + nrec + lane; r.flags = LT_F_SEARCHED; r.peak_pos = wr.peak_pos; r.score = 0;
+          r.psr = wr.psr; r.peak_value = wr.peak_value; r.cfo = 0.f; r.mean_cfo = 0.f;
+          r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f;
+          r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1;
+          r.psr_max = my_max; r.timer = a.track_every;
+          recs[nrec + lane] = r;
+          st->psr_data[(psr_i + (uint32_t)lane) % kMovingAvgSz] = wr.psr; // d_psr_data ring (lib/pss_impl.cc:166)
+        }
+        psr_max = __shfl(my_max, n_miss - 1);
+        psr = __shfl(wr.psr, n_miss - 1);
+        peak_pos = __shfl(wr.peak_pos, n_miss - 1);
+        timer = a.track_every;
+        psr_i += (uint32_t)n_miss;
+        nrec += n_miss;
+        pos += (int64_t)n_miss * kHalfFrame;
+        used = blk + n_miss;
+        k0 = n_miss;
       }
-      flags |= LT_F_OVER;
-    } else if (score != 0) {
-      score = 0;
-      timer = 0;
-      is_tracking = 0;
-      ema_reset = true;
-      psr_i = 0;
-      tracking_lost = 1;
     }
-    if (psr > psr_max) psr_max = psr;
-    int64_t out_pos = -1, next_pos;
-    if (over || tracking_lost) { // ---- lib/pss_impl.cc:184-214
-      const int frame_start = peak_pos - kSlotLen;
-      peak_pos = kSlotLen;
-      const int64_t hf0 = pos + frame_start;
-      if (hf0 + kHalfFrame > a.t1) { // (flush only) quirk q1 normalised: never read past the capture
+    bool off = false; // the chain has left the job's windows (or the run): nothing more of this round is its
+    for (int k = k0; k < nb; ++k) {
+      const int gk = blk + k;
+      const bool in_c = gk >= job.n_b;
+      const int64_t pk = in_c ? job.pos_c + (int64_t)(gk - job.n_b) * job.stride_c * kHalfFrame : job.pos_b + (int64_t)gk * job.stride_b * kHalfFrame;
+      off = true;
+      // The sequence's tracked part is entered through the hit that starts tracking, on its last window before:
+      // the scan has cleared its average there, as srslte_pss_reset did the chain's.  Any other way in (tracking
+      // started a window late, or -- track_every = 0, the strides are the same -- not at all) the two differ.
+      const bool enter_c = in_c && gk == job.n_b;
+      if (enter_c && !(ema_reset && track_k == gk - 1)) break;
+      if ((ema_reset && !enter_c) || pos != pk || (is_tracking ? a.track_every + 1 : 1) != (in_c ? job.stride_c : job.stride_b)) break; // off the job's windows
+      if (is_tracking && timer != 0) break; // (the calls before the search did not all fit)
+      if (!(pos <= limit && nrec < a.rec_cap)) {
         stop_run = true;
         break;
       }
-      next_pos = hf0 + kHalfFrame;
-      out_pos = hf0;
-      flags |= LT_F_EMITTED;
-      if (is_tracking) {
-        flags |= LT_F_SSS_RAN;
-      } else {
-        flags |= LT_F_TAG_LOST;
-        tracking_lost = 0;
+      if (!__shfl((int)wr.exact, k)) { // a lobe the strips could not close: the per-chain kernel searches this window
+        need_chain = true;
+        break;
       }
-      n_emits++;
-    } else {
-      next_pos = pos + kHalfFrame; // lib/pss_impl.cc:217
+      used = blk + k + 1;
+      if (enter_c) ema_reset = false; // (the window is the chain's: from here on the scan's average is its own again)
+      // ---- lib/pss_impl.cc:163-172: the search
+      uint32_t flags = LT_F_SEARCHED;
+      timer = a.track_every;
+      peak_pos = __shfl(wr.peak_pos, k);
+      psr = __shfl(wr.psr, k);
+      const float peak_value = __shfl(wr.peak_value, k);
+      if (lane == 0) st->psr_data[psr_i % kMovingAvgSz] = psr;
+      psr_i++;
+      const int used_peak_pos = peak_pos;
+      // ---- score, lib/pss_impl.cc:174-182 (incr_score :111-127, reset_score :129-152)
+      const bool over = psr > a.psr_threshold;
+      if (over) {
+        if (!(is_tracking && score == a.track_after)) {
+          score++;
+          if (!is_tracking && score == a.track_after) {
+            is_tracking = 1;
+            ema_reset = true; // srslte_pss_reset
+            track_k = gk;
+          }
+        }
+        flags |= LT_F_OVER;
+      } else if (score != 0) {
+        score = 0;
+        timer = 0;
+        is_tracking = 0;
+        ema_reset = true;
+        psr_i = 0;
+        tracking_lost = 1;
+      }
+      if (psr > psr_max) psr_max = psr;
+      int64_t out_pos = -1, next_pos;
+      if (over || tracking_lost) { // ---- lib/pss_impl.cc:184-214
+        const int frame_start = peak_pos - kSlotLen;
+        peak_pos = kSlotLen;
+        const int64_t hf0 = pos + frame_start;
+        if (hf0 + kHalfFrame > a.t1) { // (flush only) quirk q1 normalised: never read past the capture
+          stop_run = true;
+          break;
+        }
+        next_pos = hf0 + kHalfFrame;
+        out_pos = hf0;
+        flags |= LT_F_EMITTED;
+        if (is_tracking) {
+          flags |= LT_F_SSS_RAN;
+        } else {
+          flags |= LT_F_TAG_LOST;
+          tracking_lost = 0;
+        }
+        n_emits++;
+      } else {
+        next_pos = pos + kHalfFrame; // lib/pss_impl.cc:217
+      }
+      if (is_tracking) flags |= LT_F_TRACKING;
+      put(pos, out_pos, flags, used_peak_pos, peak_value);
+      pos = next_pos;
+      run_timer_calls();
+      off = false;
     }
-    if (is_tracking) flags |= LT_F_TRACKING;
-    put(pos, out_pos, flags, used_peak_pos, peak_value);
-    pos = next_pos;
-    run_timer_calls();
+    if (off) break;
   }
   if (lane == 0) {
     st->pos = pos;
@@ -676,10 +734,15 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
     if (ema_reset) { // zeros, whatever the scan went on to compute
       st->ema_zero = 1;
       st->pre_n = 0;
-    } else if (used == job.n_b) { // all of the round's windows: the scan's final state is the chain's
+    } else if (used == n_bc) { // all of the round's windows: the scan's final state is the chain's
       st->ema_sel = (sel + 2) % 3;
       st->ema_zero = 0;
       st->pre_n = 0;
+    } else if (used > job.n_b) { // into the tracked part: zeros run through its first windows
+      st->ema_zero = 1;
+      st->pre_pos = job.pos_c;
+      st->pre_stride = job.stride_c;
+      st->pre_n = used - job.n_b;
     } else if (used > 0) { // the first `used` windows only: from the state behind the prefix, run through them again
       if (job.n_a > 0) {
         st->ema_sel = (sel + 1) % 3;

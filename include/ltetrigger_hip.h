@@ -173,9 +173,10 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
-/* The grid scan runs in segments of windows; a chain that fires leaves the scan at the end of its segment.
- * first = windows in the first segment (default 2: cells present from the start of a capture fire at once),
- * later = windows in every following segment (default 32). */
+/* The grid scan runs in rounds of windows; a chain that fires leaves the scan at the end of its round.
+ * first = windows in the first round (default 2: cells present from the start of a capture fire at once),
+ * later = windows in every following round, at most 128 (default 0: the chunk's windows split evenly over as few
+ * rounds as they need). */
 int lt_batch_set_scan_segments(lt_batch *b, int first, int later);
 /* downlink_trigger_c.set_psr_threshold fan-out (python/downlink_trigger_c.py:63-69) */
 int lt_batch_set_psr_threshold(lt_batch *b, float threshold);

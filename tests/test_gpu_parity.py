@@ -291,7 +291,7 @@ def test_scan_and_per_chain_kernel_give_identical_records(lt, oracle, frames_192
                       np.where(t % 4800 == 17, 1.0, 0.0).astype(np.complex64), np.zeros(n, np.complex64)])
     iq = np.concatenate([iq, twins])
     res = []
-    for mode, seg in ((0, None), (1, (2, 32)), (1, (1, 5)), (1, (64, 64))):
+    for mode, seg in ((0, None), (1, None), (1, (2, 32)), (1, (1, 5)), (1, (64, 64)), (1, (128, 128))):
         b = lt.Batch(iq.shape[0], n)
         b.set_mode(mode)
         if seg:
@@ -419,3 +419,19 @@ def test_chain_random_scenes(lt, oracle, frames_192, seed):
     b, got, want = _run_both(lt, oracle, iq, **kw)
     for c in range(3 * n_ch):
         assert_records_match(got[c], want[c], f"seed {seed} {kw} chain {c}")
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_chain_long_rounds(lt, oracle, frames_192, seed):
+    """Captures of 130-150 windows: scan rounds longer than the resolver's 64 lanes (it takes a round's windows 64
+    at a time), with the default round length and with the longest one.  Full record parity."""
+    iq, kw = siggen.random_scene(2000 + seed, frames_192, list(FIXTURES), 130, 150)
+    want = oracle.batch_run(iq, nthreads=8, **kw)
+    for seg in (None, (128, 128), (3, 100)):
+        b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+        if seg:
+            b.set_scan_segments(*seg)
+        b.run_host(iq)
+        got = b.collect()
+        for c in range(3 * iq.shape[0]):
+            assert_records_match(got[c], want[c], f"seed {seed} rounds {seg} {kw} chain {c}")
