@@ -150,7 +150,7 @@ struct lt_batch {
   void *d_jobs = nullptr;    // grid scan: ScanJob[n_channels*3]
   int *d_njobs = nullptr;
   void *d_parts = nullptr;   // grid scan: the partial results of a round, per chain
-  void *d_cp = nullptr;      // per-record CP metrics, [n_channels*3][rec_cap] x 16 B
+  void *d_cp = nullptr;      // per-record scratch (CP metrics, work list), [n_channels*3][rec_cap] x per_record_scratch_bytes()
   lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
   int hist_sel = 0;
   int64_t hist_len = 0;      // valid samples in d_hist[hist_sel] (its tail)
@@ -524,9 +524,9 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_recs, sizeof(lt_record) * nchains * (size_t)b->rec_cap);
   if (e == hipSuccess) e = hipMalloc(&b->d_count, sizeof(int) * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_jobs, (size_t)lt::scan_job_bytes() * nchains * 2);
-  if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int) * 2 * (size_t)(lt::scan_max_rounds() + 1));
+  if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int) * (size_t)lt::scan_counter_ints());
   if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::scan_parts_bytes_per_chain() * nchains);
-  if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)16 * nchains * (size_t)b->rec_cap);
+  if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)lt::per_record_scratch_bytes() * nchains * (size_t)b->rec_cap);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);

@@ -200,7 +200,30 @@ struct CpArgs {
   ChainState *state;    // [n_chains]
   const DeviceTables *tab;
   int n_chains;
+  int2 *list;      // (chain, record) of every half-frame that went through the SSS stage in this run
+  int *list_count;
 };
+
+// The work list of the per-record kernels: which records carry LT_F_SSS_RAN (the tracked half-frames).  One wave per
+// 64 records of a chain, one atomic per wave.  With the list the per-record kernels start a fixed number of
+// workgroups that walk it, instead of one workgroup per four record slots of every chain, most of them empty.
+constexpr int kListBlocks = 512; // x 4 waves: two workgroups per CU
+__global__ __launch_bounds__(256) void lt_list_kernel(CpArgs a)
+{
+  const int chain = blockIdx.x;
+  const int count = a.rec_count[chain];
+  const lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < ((count + 63) & ~63); i += 256) {
+    const bool ran = i < count && (recs[i].flags & LT_F_SSS_RAN);
+    const unsigned long long m = __ballot(ran);
+    if (!m) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.list_count, __builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (ran) a.list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(chain, i);
+  }
+}
 
 // ---------------------------------------------------------------- CFO of the tracked half-frames
 // srslte_pss_cfo_compute on the uncorrected PSS symbol of every tracked half-frame (lib/pss_impl.cc:199-201):
@@ -208,18 +231,19 @@ struct CpArgs {
 __global__ __launch_bounds__(256) void lt_cfo_kernel(CpArgs a)
 {
   __shared__ v2f RAW[4][kSymbolSz];
-  const int chain = blockIdx.x, channel = chain / 3, n_id_2 = chain % 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = blockIdx.y * 4 + w;
-  if (idx >= a.rec_count[chain]) return;
-  lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
-  if (!(rec->flags & LT_F_SSS_RAN)) return;
-  const int64_t hf0 = rec->out_pos;
-  const Capture cap = make_capture(a, channel);
-  for (int i = lane; i < kSymbolSz; i += 64) RAW[w][i] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + i);
-  const float c = cfo_estimate_wave(reinterpret_cast<const v2f *>(a.tab->pss_taps[n_id_2]), RAW[w]);
-  if (lane == 0) rec->cfo = c;
+  const int n_items = *a.list_count;
+  for (int item = blockIdx.x * 4 + w; item < n_items; item += gridDim.x * 4) {
+    const int2 it = a.list[item];
+    const int chain = __builtin_amdgcn_readfirstlane(it.x), idx = __builtin_amdgcn_readfirstlane(it.y);
+    lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
+    const int64_t hf0 = rec->out_pos;
+    const Capture cap = make_capture(a, chain / 3);
+    for (int i = lane; i < kSymbolSz; i += 64) RAW[w][i] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + i);
+    const float c = cfo_estimate_wave(reinterpret_cast<const v2f *>(a.tab->pss_taps[chain % 3]), RAW[w]);
+    if (lane == 0) rec->cfo = c;
+  }
 }
 
 // d_cfo_data ring and mean_cfo() (lib/pss_impl.cc:94-109,200-204) in call order: one wave per chain.  The ring
@@ -365,21 +389,22 @@ __global__ __launch_bounds__(256) void lt_hf_kernel(HfArgs a)
 __global__ __launch_bounds__(256) void lt_cp_kernel(CpArgs a)
 {
   __shared__ v2f S[4][kSssLen];
-  const int chain = blockIdx.x, channel = chain / 3; // (chains along x: up to 2^31 - 1 of them)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = blockIdx.y * 4 + w;
-  if (idx >= a.rec_count[chain]) return;
-  const lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
-  if (!(rec->flags & LT_F_SSS_RAN)) return;
-  const int64_t hf0 = rec->out_pos;
-  const Capture cap = make_capture(a, channel);
-  const float freq = -rec->mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
-  const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-  for (int i = lane; i < kSssLen; i += 64)
-    S[w][i] = cfo_rotate(a.tab->cexptab, phase_inc, kSssBase + i, ld_abs(cap, hf0 + kSssBase + i));
-  const CpMetrics cm = cp_metrics_wave(S[w]);
-  if (lane == 0) a.metrics[(int64_t)chain * a.rec_cap + idx] = cm;
+  const int n_items = *a.list_count;
+  for (int item = blockIdx.x * 4 + w; item < n_items; item += gridDim.x * 4) {
+    const int2 it = a.list[item];
+    const int chain = __builtin_amdgcn_readfirstlane(it.x), idx = __builtin_amdgcn_readfirstlane(it.y);
+    const lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
+    const int64_t hf0 = rec->out_pos;
+    const Capture cap = make_capture(a, chain / 3);
+    const float freq = -rec->mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
+    const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+    for (int i = lane; i < kSssLen; i += 64)
+      S[w][i] = cfo_rotate(a.tab->cexptab, phase_inc, kSssBase + i, ld_abs(cap, hf0 + kSssBase + i));
+    const CpMetrics cm = cp_metrics_wave(S[w]);
+    if (lane == 0) a.metrics[(int64_t)chain * a.rec_cap + idx] = cm;
+  }
 }
 
 // One wave per chain: 64 records at a time are fetched one per lane and everything that does not depend on
@@ -451,51 +476,63 @@ struct SssArgs {
   int rec_cap;
   const int *rec_count; // [n_chains]
   const DeviceTables *tab;
+  const int2 *list;     // as CpArgs
+  const int *list_count;
 };
 
 __global__ __launch_bounds__(256) void lt_sss_kernel(SssArgs a)
 {
-  __shared__ LdsTables ltab;
+  __shared__ LdsTables ltab[4]; // (the m-sequence masks depend on the chain's N_id_2: one set per wave)
   __shared__ v2f SYM[4][kSymbolSz];
   __shared__ v2f Y[4][62];
-  const int chain = blockIdx.x, n_id_2 = chain % 3, channel = chain / 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int idx = blockIdx.y * 4 + w;
-  const int count = a.rec_count[chain];
-  if ((int)blockIdx.y * 4 >= count) return; // whole block beyond this chain's records
-  load_lds_tables(ltab, a.tab, n_id_2);
-  __syncthreads();
-  if (idx >= count) return;
-  lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
-  const uint32_t flags = rec->flags;
-  if (!(flags & LT_F_SSS_RAN)) return;
-  const int64_t hf0 = rec->out_pos;
-  const float mean_cfo = rec->mean_cfo;
-  const Capture cap = make_capture(a, channel);
-  const float freq = -mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
-  const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-  const int cp_len = (flags & LT_F_CP_EXT) ? 32 : 9;              // srslte_sync_set_cp
-  const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len;           // lib/sss_impl.cc:110
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int i = sss_idx + lane + 64 * k;
-    SYM[w][lane + 64 * k] = cfo_rotate(a.tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
-  }
-  SssResult r;
-  r.cp = 0;
-  sss_fft128_wave(SYM[w], ltab.tw128, Y[w]);
-  sss_m0m1_wave(Y[w], ltab, r);
-  r.n_id_1 = sss_n_id_1(a.tab, (uint32_t)r.m0, (uint32_t)r.m1);
+  const int n_items = *a.list_count;
+  if ((int)blockIdx.x * 4 >= n_items) return;
+  for (int i = lane; i < 64; i += 64) ltab[w].tw128[i] = v2f{(float)a.tab->dft128_cos[i], (float)a.tab->dft128_sin[i]};
   if (lane == 0) {
-    rec->m0 = r.m0;
-    rec->m1 = r.m1;
-    rec->m0_value = r.m0_value;
-    rec->m1_value = r.m1_value;
-    rec->n_id_1 = r.n_id_1;
-    if (r.n_id_1 >= 0) {
-      rec->cell_id = 3 * r.n_id_1 + n_id_2; // srslte_sync_get_cell_id
-      rec->flags = flags | LT_F_TAG_CELL;
+    ltab[w].s_mask = a.tab->sss_s_mask;
+    ltab[w].z_mask = a.tab->sss_z_mask;
+  }
+  for (int item = blockIdx.x * 4 + w; item < n_items; item += gridDim.x * 4) {
+    const int2 it = a.list[item];
+    const int chain = __builtin_amdgcn_readfirstlane(it.x), idx = __builtin_amdgcn_readfirstlane(it.y);
+    const int n_id_2 = chain % 3;
+    lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
+    const uint32_t flags = rec->flags;
+    const int64_t hf0 = rec->out_pos;
+    const float mean_cfo = rec->mean_cfo;
+    const Capture cap = make_capture(a, chain / 3);
+    const float freq = -mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
+    const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
+    const int cp_len = (flags & LT_F_CP_EXT) ? 32 : 9;              // srslte_sync_set_cp
+    const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len;           // lib/sss_impl.cc:110
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      ltab[w].c0_mask = a.tab->sss_c0_mask[n_id_2];
+      ltab[w].c1_mask = a.tab->sss_c1_mask[n_id_2];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = sss_idx + lane + 64 * k;
+      SYM[w][lane + 64 * k] = cfo_rotate(a.tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
+    }
+    __builtin_amdgcn_wave_barrier();
+    SssResult r;
+    r.cp = 0;
+    sss_fft128_wave(SYM[w], ltab[w].tw128, Y[w]);
+    sss_m0m1_wave(Y[w], ltab[w], r);
+    r.n_id_1 = sss_n_id_1(a.tab, (uint32_t)r.m0, (uint32_t)r.m1);
+    if (lane == 0) {
+      rec->m0 = r.m0;
+      rec->m1 = r.m1;
+      rec->m0_value = r.m0_value;
+      rec->m1_value = r.m1_value;
+      rec->n_id_1 = r.n_id_1;
+      if (r.n_id_1 >= 0) {
+        rec->cell_id = 3 * r.n_id_1 + n_id_2; // srslte_sync_get_cell_id
+        rec->flags = flags | LT_F_TAG_CELL;
+      }
     }
   }
 }
@@ -542,6 +579,8 @@ int scan_job_bytes() { return (int)sizeof(ScanJob); }
 int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips * kScanMaxRound); }
 int scan_max_round() { return kScanMaxRound; }
 int scan_max_rounds() { return kMaxRounds; }
+int scan_counter_ints() { return 2 * (kMaxRounds + 1) + 2; } // job counters of every round + the per-record work list's
+int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + sizeof(int2)); }
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
 {
@@ -585,7 +624,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     int rounds = 1;
     if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
     if (rounds > kMaxRounds) rounds = kMaxRounds;
-    hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int) * 2 * (kMaxRounds + 1), stream);
+    hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int) * (2 * (kMaxRounds + 1) + 2), stream);
     if (e != hipSuccess) return e;
     // one job per channel; long and short jobs each start on a fresh group of 8 workgroups
     const int grid = (((R.n_channels + 7) / 8) * 8 + 8) * kScanWgPerJob;
@@ -654,10 +693,15 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     c.iq = iq; c.ch_stride = R.ch_stride; c.hist = hist; c.hist_stride = R.hist_stride; c.t0 = R.t0; c.n = R.n;
     c.hist_len = R.hist_len; c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.metrics = reinterpret_cast<CpMetrics *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
+    // (the work list sits behind the metrics in the same scratch buffer; its counter behind the job counters)
+    c.list = reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * (size_t)n_chains * (size_t)R.rec_cap);
+    c.list_count = R.n_jobs + 2 * (kMaxRounds + 1);
     SssArgs q;
     q.iq = iq; q.ch_stride = R.ch_stride; q.hist = hist; q.hist_stride = R.hist_stride; q.t0 = R.t0; q.n = R.n;
     q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;
-    const dim3 per_record((unsigned)n_chains, (unsigned)((R.rec_cap + 3) / 4));
+    q.list = c.list; q.list_count = c.list_count;
+    const dim3 per_record((unsigned)kListBlocks);
+    hipLaunchKernelGGL(lt_list_kernel, dim3((unsigned)n_chains), dim3(256), 0, stream, c);
     hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, stream, c);
     hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, stream, c);
     hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, stream, c);

@@ -36,12 +36,12 @@ struct RunLaunch {
   int track_every = 8;
   int scan = 1;               // 0: every chain goes through the per-chain kernel
   void *jobs = nullptr;       // device, 2 x ScanJob[n_channels*3]
-  int *n_jobs = nullptr;      // device, 2 x (scan_max_rounds() + 1) counters
+  int *n_jobs = nullptr;      // device, scan_counter_ints() counters
   void *parts = nullptr;      // device, scan_parts_bytes_per_chain() per chain
   int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
   int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
   int extra_rounds = 2;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
-  void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x 16 B: per-record CP metrics
+  void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the work list
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr;
 };
@@ -54,6 +54,8 @@ int scan_job_bytes();
 int scan_parts_bytes_per_chain();
 int scan_max_round();
 int scan_max_rounds();
+int scan_counter_ints();
+int per_record_scratch_bytes();
 size_t chain_state_bytes();
 size_t chain_state_avg_offset();
 

@@ -44,6 +44,31 @@ def first_difference(got, want):
     return None
 
 
+def near_tie(O, x, n_id_2, want, call, lag_gpu):
+    """A peak position that differs from the oracle's: are the two lags' averages within the lag metric's
+    tolerance (1e-4 relative) in the oracle's own average at that call?  Replays the oracle's searches up to the
+    call (srslte_pss_reset where tracking starts and where the score is reset, lib/pss_impl.cc:119-152)."""
+    p = O.Pss(n_id_2)
+    tracking = False
+    for i in range(call + 1):
+        r = want[i]
+        if r["flags"] & 1:  # LT_F_SEARCHED
+            pos = int(r["in_pos"])
+            seg = x[pos:pos + 9600]
+            if seg.size < 9600:
+                return False
+            p.find_pss(seg)
+            if i == call:
+                a = p.avg()
+                top = float(a[int(r["peak_pos"])])
+                return abs(top - float(a[int(lag_gpu)])) <= 1e-4 * abs(top)
+        now = bool(r["flags"] & 4)  # LT_F_TRACKING
+        if (now and not tracking) or (r["flags"] & 16):  # tracking starts / score reset (tracking_lost tag)
+            p.reset()
+        tracking = now
+    return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenes", type=int, default=100)
@@ -80,6 +105,7 @@ def main():
 
     t_start = time.time()
     bad = []
+    ties = []  # arg-max between two lags whose averages agree to 1e-4: inside the lag metric's tolerance
     n_records = 0
     n_samples = 0
     n_scenes = 0
@@ -97,7 +123,15 @@ def main():
                 n_records += len(want[c])
                 d = first_difference(got[c], want[c])
                 if d:
-                    bad.append({"seed": seed, "mode": mode, "chain": c, "kw": kw, "what": d})
+                    item = {"seed": seed, "mode": mode, "chain": c, "kw": kw, "what": d}
+                    if d.startswith("peak_pos at call "):
+                        call = int(d.split()[3].rstrip(":"))
+                        item["near_tie"] = bool(near_tie(O, iq[c // 3], c % 3, want[c], call, got[c]["peak_pos"][call]))
+                    if item.get("near_tie"):
+                        ties.append(item)
+                        print(json.dumps(item), file=sys.stderr, flush=True)
+                        break
+                    bad.append(item)
                     print(json.dumps(bad[-1]), file=sys.stderr, flush=True)
                     if args.out and len(bad) <= 3 and not args.replay:
                         os.makedirs(args.out, exist_ok=True)
@@ -106,7 +140,7 @@ def main():
         if n_scenes % 20 == 0:
             print(f"{n_scenes} scenes, {len(bad)} differ, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
     res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0],
-           "differing": bad, "seconds": round(time.time() - t_start, 1)}
+           "differing": bad, "arg_max_between_lags_equal_to_1e-4": ties, "seconds": round(time.time() - t_start, 1)}
     print(json.dumps(res))
     if args.out:
         os.makedirs(args.out, exist_ok=True)
