@@ -616,8 +616,8 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   if (restart) {
     b->t0 = 0;
     b->hist_len = 0;
-    HIP_TRY(lt::launch_rebase(b->d_state, (int)nchains, s));
   }
+  HIP_TRY(lt::launch_begin(b->d_state, (int)nchains, restart ? 1 : 0, b->d_njobs, s));
   const lt_cf32 *d_iq = iq;
   if (!iq_on_device) {
     const size_t bytes = sizeof(lt_cf32) * (size_t)b->n_channels * (size_t)n_samples;

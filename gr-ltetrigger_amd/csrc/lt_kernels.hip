@@ -624,8 +624,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     int rounds = 1;
     if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
     if (rounds > kMaxRounds) rounds = kMaxRounds;
-    hipError_t e = hipMemsetAsync(R.n_jobs, 0, sizeof(int) * (2 * (kMaxRounds + 1) + 2), stream);
-    if (e != hipSuccess) return e;
+    // (the counters behind R.n_jobs are zero: launch_begin)
     // one job per channel; long and short jobs each start on a fresh group of 8 workgroups
     const int grid = (((R.n_channels + 7) / 8) * 8 + 8) * kScanWgPerJob;
     p.first_round = 1;
@@ -726,14 +725,20 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
   return hipGetLastError();
 }
 
-__global__ void lt_rebase_kernel(ChainState *state, int n_chains)
+// First launch of a run: the counters of its scan rounds and of its work list start at zero, and a run that is a
+// capture of its own (lt_batch_run) starts its positions at 0 again.
+__global__ void lt_begin_kernel(ChainState *state, int n_chains, int rebase, int *counters, int n_counters)
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n_chains) state[c].pos = 0;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rebase && i < n_chains) state[i].pos = 0;
+  if (i < n_counters) counters[i] = 0;
 }
-hipError_t launch_rebase(void *state, int n_chains, hipStream_t stream)
+hipError_t launch_begin(void *state, int n_chains, int rebase, int *counters, hipStream_t stream)
 {
-  hipLaunchKernelGGL(lt_rebase_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), n_chains);
+  const int n_counters = scan_counter_ints();
+  const int n = n_chains > n_counters ? n_chains : n_counters;
+  hipLaunchKernelGGL(lt_begin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), n_chains, rebase,
+                     counters, n_counters);
   return hipGetLastError();
 }
 

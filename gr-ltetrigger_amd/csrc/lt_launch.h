@@ -48,7 +48,9 @@ struct RunLaunch {
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream);
 // every chain back to stream position 0 (lt_batch_run: the chunk is a capture of its own)
-hipError_t launch_rebase(void *state, int n_chains, hipStream_t stream);
+// to be launched before launch_run, on the same stream: zeroes the run's counters (RunLaunch::n_jobs) and, for a run that
+// restarts at position 0, the chains' positions
+hipError_t launch_begin(void *state, int n_chains, int rebase, int *counters, hipStream_t stream);
 int call_reach();
 int scan_job_bytes();
 int scan_parts_bytes_per_chain();

@@ -625,9 +625,9 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
           recs[nrec + lane] = r;
           st->psr_data[(psr_i + (uint32_t)lane) % kMovingAvgSz] = wr.psr; // d_psr_data ring (lib/pss_impl.cc:166)
         }
-        psr_max = __shfl(my_max, n_miss - 1);
-        psr = __shfl(wr.psr, n_miss - 1);
-        peak_pos = __shfl(wr.peak_pos, n_miss - 1);
+        psr_max = rlane(my_max, n_miss - 1); // (wave-uniform lane: v_readlane, not a trip through the LDS)
+        psr = rlane(wr.psr, n_miss - 1);
+        peak_pos = __builtin_amdgcn_readlane(wr.peak_pos, n_miss - 1);
         timer = a.track_every;
         psr_i += (uint32_t)n_miss;
         nrec += n_miss;
@@ -653,7 +653,7 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
         stop_run = true;
         break;
       }
-      if (!__shfl((int)wr.exact, k)) { // a lobe the strips could not close: the per-chain kernel searches this window
+      if (!__builtin_amdgcn_readlane((int)wr.exact, k)) { // a lobe the strips could not close: the per-chain kernel searches this window
         need_chain = true;
         break;
       }
@@ -662,9 +662,9 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
       // ---- lib/pss_impl.cc:163-172: the search
       uint32_t flags = LT_F_SEARCHED;
       timer = a.track_every;
-      peak_pos = __shfl(wr.peak_pos, k);
-      psr = __shfl(wr.psr, k);
-      const float peak_value = __shfl(wr.peak_value, k);
+      peak_pos = __builtin_amdgcn_readlane(wr.peak_pos, k);
+      psr = rlane(wr.psr, k);
+      const float peak_value = rlane(wr.peak_value, k);
       if (lane == 0) st->psr_data[psr_i % kMovingAvgSz] = psr;
       psr_i++;
       const int used_peak_pos = peak_pos;
