@@ -19,6 +19,10 @@
 #pragma once
 #include "lt_device.h"
 
+#ifndef LT_LOAD_AUX
+#define LT_LOAD_AUX 0 // cache policy of the sample loads (2 = nt)
+#endif
+
 namespace lt {
 
 constexpr int kStrips = 12;
@@ -254,7 +258,7 @@ __device__ __forceinline__ void strip_load(const Capture &c, int64_t w0, int s, 
 #pragma unroll
     for (int R = 0; R < 16; ++R) {
       typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(win, off + 64 * R * (int)sizeof(v2f), 0, 2 /* nt */);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(win, off + 64 * R * (int)sizeof(v2f), 0, LT_LOAD_AUX);
       x[R] = __builtin_bit_cast(v2f, v);
     }
   } else {
