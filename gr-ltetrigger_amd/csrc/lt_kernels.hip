@@ -207,7 +207,7 @@ struct CpArgs {
 // The work list of the per-record kernels: which records carry LT_F_SSS_RAN (the tracked half-frames).  One wave per
 // 64 records of a chain, one atomic per wave.  With the list the per-record kernels start a fixed number of
 // workgroups that walk it, instead of one workgroup per four record slots of every chain, most of them empty.
-constexpr int kListBlocks = 512; // x 4 waves: two workgroups per CU
+constexpr int kListBlocks = 2048; // x 4 waves: eight workgroups per CU
 __global__ __launch_bounds__(256) void lt_list_kernel(CpArgs a)
 {
   const int chain = blockIdx.x;
@@ -293,8 +293,51 @@ __global__ __launch_bounds__(64) void lt_cfo_ring_kernel(CpArgs a)
   for (int base = 0; base < count; base += 64) {
     const int i = base + lane;
     const uint32_t flags = i < count ? recs[i].flags : 0u;
-    const float c = (flags & LT_F_SSS_RAN) ? recs[i].cfo : 0.f;
-    const unsigned long long ran = __ballot((flags & LT_F_SSS_RAN) != 0), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
+    const bool is_ran = (flags & LT_F_SSS_RAN) != 0;
+    const float c = is_ran ? recs[i].cfo : 0.f;
+    const unsigned long long ran = __ballot(is_ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
+    if (!ran && !lost) continue;
+    // ---- the 64 records at once.  While the exponent window holds for every entry up to the last of these
+    // records, all the sums are exact whatever their order: record j's sum is the carried one plus the entries
+    // of the records up to j minus the ring entries those overwrite -- two prefix sums across the lanes.
+    if (narrow && !lost) {
+      const uint32_t bits = __float_as_uint(c) & 0x7fffffffu, e = bits >> 23;
+      const bool counts = is_ran && bits != 0u;
+      const uint32_t bmin = (uint32_t)wave_min_i(counts ? (int)e : 255), bmax = (uint32_t)wave_max_i(counts ? (int)e : 0);
+      const uint32_t nmin = bmin < emin ? bmin : emin, nmax = bmax > emax ? bmax : emax;
+      const bool sub = __ballot(counts && e == 0u) != 0;
+      if (!sub && (nmax == 0u || (nmax - nmin <= 20u && nmax < 255u))) {
+        const uint32_t rank = (uint32_t)__builtin_popcountll(ran & ((1ull << lane) - 1ull));
+        const uint32_t idx = cfo_i + rank; // this record's entry (if it has one)
+        const uint32_t slot = idx % kMovingAvgSz;
+        double add = is_ran ? (double)c : 0.0;
+        double drop = (is_ran && idx >= (uint32_t)kMovingAvgSz) ? (double)ring[slot] : 0.0; // the entry it overwrites
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const double a2 = __hiloint2double(__shfl_up(__double2hiint(add), d), __shfl_up(__double2loint(add), d));
+          const double d2 = __hiloint2double(__shfl_up(__double2hiint(drop), d), __shfl_up(__double2loint(drop), d));
+          if (lane >= d) {
+            add += a2;
+            drop += d2;
+          }
+        }
+        const double mine_acc = (acc + add) - drop;
+        const uint32_t npts = idx + 1 < (uint32_t)kMovingAvgSz ? idx + 1 : (uint32_t)kMovingAvgSz;
+        __builtin_amdgcn_wave_barrier();
+        if (is_ran) {
+          ring[slot] = c; // (64 records at most, 200 slots: no two of them share one)
+          recs[i].mean_cfo = (float)(mine_acc / (double)npts);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int last = 63 - __builtin_clzll(ran);
+        acc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine_acc), last), __builtin_amdgcn_readlane(__double2loint(mine_acc), last));
+        cfo_i += (uint32_t)__builtin_popcountll(ran);
+        emin = nmin;
+        emax = nmax;
+        continue;
+      }
+    }
+    // ---- in call order, one record after the other
     unsigned long long events = ran | lost;
     float mine = 0.f;
     double my_acc = 0.0; // narrow mode: this lane's record's sum and count; the division waits until after the walk
