@@ -657,6 +657,63 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
         need_chain = true;
         break;
       }
+      // ---- a tracked chain in its steady state (score at track_after, every search a hit that leaves the peak where
+      // it is): the searches up to the first window that is anything else, one lane each -- the search's record and
+      // those of the track_every calls behind it (lib/pss_impl.cc:163-204 with frame_start = 0).
+      if (is_tracking && score == a.track_after && !tracking_lost && !ema_reset && !enter_c) {
+        const int S = a.track_every + 1;                  // calls (and records) per window
+        const int seg_end = in_c ? nb : (job.n_b - blk < nb ? job.n_b - blk : nb); // same part of the sequence as window k
+        const int t = lane - k;                           // this lane's window, counted from k
+        const int64_t my_pos = pos + (int64_t)t * S * kHalfFrame;
+        const bool mine = lane >= k && lane < seg_end;
+        const bool fits = mine && my_pos + (int64_t)a.track_every * kHalfFrame <= limit && my_pos + kHalfFrame <= a.t1 &&
+                          nrec + (int64_t)(t + 1) * S <= a.rec_cap;
+        const bool steady = fits && wr.exact && wr.psr > a.psr_threshold && wr.peak_pos == kSlotLen;
+        const unsigned long long bad = ~__ballot(steady) & (~0ull << k);
+        const int m = (bad ? __builtin_ctzll(bad) : 64) - k; // windows k .. k + m - 1
+        if (m > 1) {
+          const bool on = lane >= k && lane < k + m;
+          float pm = on ? wr.psr : -FLT_MAX; // d_psr_max as an inclusive prefix maximum
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(pm, d);
+            if (lane >= d) pm = fmaxf(pm, o);
+          }
+          const float my_max = fmaxf(psr_max, pm);
+          if (on) {
+            lt_record r;
+            r.channel = channel; r.n_id_2 = n_id_2; r.score = score; r.psr = wr.psr; r.cfo = 0.f; r.mean_cfo = 0.f;
+            r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f; r.m1_value = 0.f; r.m0 = -1; r.m1 = -1; r.n_id_1 = -1;
+            r.cell_id = -1; r.psr_max = my_max; r.peak_pos = kSlotLen;
+            const int base = nrec + t * S;
+            r.in_pos = my_pos; r.out_pos = my_pos; r.call_idx = call_base + base;
+            r.flags = LT_F_SEARCHED | LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
+            r.peak_value = wr.peak_value; r.timer = a.track_every;
+            recs[base] = r;
+            r.flags = LT_F_OVER | LT_F_EMITTED | LT_F_SSS_RAN | LT_F_TRACKING;
+            r.peak_value = 0.f;
+            for (int i = 0; i < a.track_every; ++i) {
+              r.in_pos = r.out_pos = my_pos + (int64_t)(1 + i) * kHalfFrame;
+              r.call_idx = call_base + base + 1 + i;
+              r.timer = a.track_every - 1 - i;
+              recs[base + 1 + i] = r;
+            }
+            st->psr_data[(psr_i + (uint32_t)t) % kMovingAvgSz] = wr.psr;
+          }
+          psr_max = rlane(my_max, k + m - 1);
+          psr = rlane(wr.psr, k + m - 1);
+          peak_pos = kSlotLen;
+          timer = 0;
+          psr_i += (uint32_t)m;
+          nrec += m * S;
+          n_emits += m * S;
+          pos += (int64_t)m * S * kHalfFrame;
+          used = blk + k + m;
+          k += m - 1;
+          off = false;
+          continue;
+        }
+      }
       used = blk + k + 1;
       if (enter_c) ema_reset = false; // (the window is the chain's: from here on the scan's average is its own again)
       // ---- lib/pss_impl.cc:163-172: the search
