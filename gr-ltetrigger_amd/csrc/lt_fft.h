@@ -144,47 +144,25 @@ template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const Twiddles
   e[l] = v[0];
 #pragma unroll
   for (int k1 = 1; k1 < 16; ++k1) {
-#ifndef LT_ABL_NO_TW
     v[k1] = cmulw<kInv>(v[k1], t.w[k1 - 1]);
-#endif
     e[k1 * kRowA + l] = v[k1];
   }
 }
-// kLean: the twiddles are read four at a time after the butterflies instead (8 registers instead of 30, the
-// read latency exposed: for the forward waves of the scan kernel, which hold three blocks of samples and are
-// not the ones the others wait for).
-template <bool kInv, bool kLean = false> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32 *tw2, const c32 *e1, c32 *e2)
+template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32 *tw2, const c32 *e1, c32 *e2)
 {
   const int k1 = l >> 2, c = l & 3;
 #pragma unroll
   for (int s = 0; s < 16; ++s) v[s] = e1[k1 * kRowA + c + 4 * s];
   Twiddles t;
-  if (!kLean) stageB_twiddles(l, tw2, t);
+  stageB_twiddles(l, tw2, t);
   LT_FFT_FENCE;
   fft16<1, kInv>(v);
   LT_FFT_FENCE;
   e2[c * kRowC + k1] = v[0];
 #pragma unroll
   for (int k = 1; k < 16; ++k) {
-#ifndef LT_ABL_NO_TW
-    v[k] = cmulw<kInv>(v[k], kLean ? tw2[k * 4 + c] : t.w[k - 1]);
-#endif
+    v[k] = cmulw<kInv>(v[k], t.w[k - 1]);
     e2[c * kRowC + k1 + 16 * k] = v[k];
-    if (kLean && (k & 3) == 3) LT_FFT_FENCE;
-  }
-}
-template <bool kInv> LT_HD void fft1024w_stageA_lean(int l, c32 v[16], const c32 *tw1, c32 *e)
-{
-  fft16<1, kInv>(v);
-  LT_FFT_FENCE;
-  e[l] = v[0];
-#pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) {
-#ifndef LT_ABL_NO_TW
-    v[k1] = cmulw<kInv>(v[k1], tw1[k1 * 64 + l]);
-#endif
-    e[k1 * kRowA + l] = v[k1];
-    if ((k1 & 3) == 3) LT_FFT_FENCE;
   }
 }
 // (stage A reading its own twiddles: for callers with nothing to overlap the reads with)

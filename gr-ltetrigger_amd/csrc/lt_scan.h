@@ -328,18 +328,14 @@ __device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32
 __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
                                                   const fft::c32 *tw2, fft::c32 *e, ema_t &ema)
 {
-#ifndef LT_ABL_NO_SPEC
 #pragma unroll
   for (int R = 0; R < 16; ++R) v[R] = fft::cmulw<false>(v[R], spec[R]);
-#endif
-#ifndef LT_ABL_NO_IFFT
   fft::fft1024w_stageA<true>(lane, v, tw, e);
   __builtin_amdgcn_sched_barrier(0);
   fft::fft1024w_stageB<true>(lane, v, tw2, e, e);
   __builtin_amdgcn_sched_barrier(0);
   fft::fft1024w_stageC<true>(lane, v, e);
   __builtin_amdgcn_sched_barrier(0);
-#endif
   strip_ema_update(s, lane, v, ema);
 }
 __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f *spec_tab,

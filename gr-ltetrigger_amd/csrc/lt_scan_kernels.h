@@ -31,9 +31,6 @@
 // prefetch of the next windows and the root waves' partial-result stores, i.e. a full memory latency per window.
 #define LT_LDS_ORDER __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
-#ifndef LT_SCAN_STAGGER
-#define LT_SCAN_STAGGER 0 // s_sleep units (64 clocks) by which group g starts later than group g - 1
-#endif
 
 namespace lt {
 
@@ -170,9 +167,6 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   //   ready[g][q] = windows of sequence q whose first two transform stages the forward wave has left in OUT[g]
   //   taken[g][r] = windows root wave r has read from there (a root wave may be one window ahead of its sequence's others)
   // Hand-over number h (all sequences of the job counted together, in the forward wave's order) uses OUT[g][h & 1].
-#if LT_SCAN_STAGGER
-  for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(LT_SCAN_STAGGER);
-#endif
   if (role == 0) {
     // Blocks are fetched one hand-over of their kind ahead, each into the registers the block before has just
     // left (two register sets taking turns for sequence 0, so that no block is ever moved; one for the others'
@@ -198,11 +192,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #endif
     auto hand_over = [&](int q, int k, int roots_q, int ln, fft::c32 (&x)[16]) {
       LT_FSTAMP(0) // loads issued
-#ifdef LT_SCAN_FWD_LEAN
-      fft::fft1024w_stageA_lean<false>(ln, x, TW1, e);
-#else
       fft::fft1024w_stageA<false>(ln, x, TW1, e);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       LT_FSTAMP(1) // first stage (and the wait for the block's samples)
       // the block that used this buffer two hand-overs ago has been taken by all its root waves
@@ -213,11 +203,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
           while (__hip_atomic_load(&sync_taken[g][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hn) __builtin_amdgcn_s_sleep(1);
       LT_FSTAMP(2) // waiting for the buffer
       LT_LDS_ORDER;
-#ifdef LT_SCAN_FWD_LEAN
-      fft::fft1024w_stageB<false, true>(ln, x, TW2, e, OUT[g][h & 1]);
-#else
       fft::fft1024w_stageB<false>(ln, x, TW2, e, OUT[g][h & 1]);
-#endif
       LT_LDS_ORDER;
       LT_FSTAMP(3) // second stage
       if (lane == 0) __hip_atomic_store(&sync_ready[g][q], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -258,9 +244,6 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     }
 #endif
   } else if (active) {
-#ifdef LT_ROOT_PRIO
-    __builtin_amdgcn_s_setprio(LT_ROOT_PRIO);
-#endif
     const ScanSeq sq = uniform_seq(jp->seq[my_seq]);
     const int n_w = seq_windows(sq);
     // hand-over number of this sequence's window k (the forward wave's order: per k, sequence 0, 1, 2 as far as
@@ -322,11 +305,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
         if (k == sq.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
       } else {
         StripPartial p;
-#ifndef LT_ABL_NO_RESOLVE
         strip_resolve(ema, strip, ln, p);
-#else
-        p.m1 = ema[3]; p.p1 = 0; p.s = ema[5]; p.lb = p.ub = 0; p.a0 = 0.f; p.flags = 0; p.pad = 0;
-#endif
         if (lane == 0) parts[(int64_t)(k - sq.n_a) * kStrips] = p;
       }
       LT_PSTAMP(7) // resolve + store

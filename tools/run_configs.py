@@ -43,11 +43,21 @@ def oracle_cell(O, M, x192, root_hint=None):
     return None if best is None else best[1]
 
 
+def _load_stress():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_parity.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
 def main():
+    stress = _load_stress()
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=50)
     ap.add_argument("--out", default=None)
     ap.add_argument("--skip-oracle", action="store_true")
+    ap.add_argument("--snrs", default="", help="config 5: comma-separated SNRs in dB (default -10..10 in steps of 2)")
     args = ap.parse_args()
     import torch
     import ltetrigger_amd as lt
@@ -103,7 +113,7 @@ def main():
     dec = lt.Decim(16)
     T = args.trials
     bt = lt.BatchTrigger(T, n_out, psr_threshold=4.0, exit_on_success=True)
-    snrs = list(range(-10, 11, 2))
+    snrs = [int(v) for v in args.snrs.split(",")] if args.snrs else list(range(-10, 11, 2))
     curve = []
     for snr in snrs:
         y = torch.empty((T, n_out), dtype=torch.complex64, device=dev)
@@ -124,19 +134,30 @@ def main():
             yh = y.cpu().numpy()
             want = O.batch_run(yh, nthreads=min(os.cpu_count() or 1, 16))
             same_records = True
+            differing = []
             cpu_det = []
             for t in range(T):
                 ok = False
                 for root in range(3):
                     g_, w_ = recs[t * 3 + root], want[t * 3 + root]
-                    if len(g_) != len(w_) or not all(np.array_equal(g_[f], w_[f]) for f in
-                                                    ("in_pos", "out_pos", "flags", "peak_pos", "score", "m0", "m1", "cell_id")):
-                        same_records = False
+                    d = stress.first_difference(g_, w_)
+                    if d:
+                        item = {"trial": t, "root": root, "what": d}
+                        if d.startswith("peak_pos at call "):
+                            call = int(d.split()[3].rstrip(":"))
+                            item["near_tie"] = bool(stress.near_tie(O, yh[t], root, w_, call, g_["peak_pos"][call]))
+                        # an arg-max between two lags whose averages agree to 1e-4 is inside the lag metric's tolerance
+                        if not item.get("near_tie"):
+                            same_records = False
+                            if args.out and len(differing) < 3:
+                                np.save(os.path.splitext(args.out)[0] + f"_snr{snr}_trial{t}.npy", yh[t])
+                        differing.append(item)
                 c = oracle_cell(O, M, yh[t]) if gpu_det[t] or True else None
                 ok = bool(c and c["cell_id"] == 369 and c["nof_prb"] == 100)
                 cpu_det.append(ok)
             point.update({"cpu_detected": int(sum(cpu_det)), "cpu_rate": round(sum(cpu_det) / T, 3),
-                          "trial_for_trial_equal": bool(cpu_det == gpu_det), "records_equal": same_records})
+                          "trial_for_trial_equal": bool(cpu_det == gpu_det), "records_equal": same_records,
+                          "record_differences": differing})
         curve.append(point)
         print(json.dumps(point), file=sys.stderr, flush=True)
     res["config5"] = {"input": "lte_frame_100prb_cellid_369 looped x100 @30.72 Msps + AWGN (SNR over the full band), "
