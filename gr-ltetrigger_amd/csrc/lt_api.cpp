@@ -167,6 +167,17 @@ struct lt_batch {
   bool ran = false;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
+  // lt_batch_set_overlap: the per-record kernels of a run on a stream of their own, beside the next run's scan rounds.
+  // Two sets of records take turns; rec_done[i] = "the per-record kernels that worked on set i are through".
+  int overlap = 0;
+  hipStream_t side = nullptr;
+  lt_record *d_recs_b = nullptr;
+  int *d_count_b = nullptr;
+  hipEvent_t rec_done[2] = {nullptr, nullptr};
+  bool rec_done_valid[2] = {false, false};
+  bool side_busy = false;          // something may still be running on `side`
+  lt_record *cur_recs = nullptr;   // the set the last run wrote
+  int *cur_count = nullptr;
 };
 
 struct lt_decim {
@@ -534,6 +545,8 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
     for (int j = 0; j < 4 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
   b->ev0 = b->ev[0][0];
   b->ev1 = b->ev[0][3];
+  b->cur_recs = b->d_recs;
+  b->cur_count = b->d_count;
   if (e != hipSuccess) {
     (void)hipGetLastError();
     lt_batch_free(b);
@@ -548,12 +561,17 @@ void lt_batch_free(lt_batch *b)
   if (!b) return;
   (void)hipSetDevice(b->device);
   if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
-  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1]};
+  if (b->side) (void)hipStreamSynchronize(b->side);
+  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1],
+                  b->d_recs_b, b->d_count_b};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (auto &set : b->ev)
     for (hipEvent_t e : set)
       if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->rec_done)
+    if (e) (void)hipEventDestroy(e);
+  if (b->side) (void)hipStreamDestroy(b->side);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -581,6 +599,7 @@ int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain)
   if (!b || max_per_chain < 0) return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
   HIP_TRY(hipSetDevice(b->device));
   if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
+  if (b->side_busy) HIP_TRY(hipStreamSynchronize(b->side));
   if (b->d_hf) {
     HIP_TRY(hipFree(b->d_hf));
     b->d_hf = nullptr;
@@ -608,16 +627,31 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   // runs on different streams are ordered by the host here: state, records and history are shared
   if (b->last_stream && b->last_stream != s) HIP_TRY(hipStreamSynchronize(b->last_stream));
   const size_t nchains = (size_t)b->n_channels * 3;
+  // Overlap: for captures of their own handed over on the device (a streamed chunk's per-record kernels read the
+  // history buffer the next chunk rewrites; a host buffer is staged through one device buffer).
+  const bool ov = b->overlap && restart && iq_on_device;
+  const int set = ov ? (int)(b->n_runs & 1) : 0;
+  if (b->side_busy && !ov) { // back to one stream: let them finish
+    HIP_TRY(hipStreamSynchronize(b->side));
+    b->side_busy = false;
+  }
+  if (ov && b->rec_done_valid[set]) HIP_TRY(hipStreamWaitEvent(s, b->rec_done[set], 0)); // this set's last user, two runs ago
   if (b->pending_reset) {
-    HIP_TRY(hipMemsetAsync(b->d_state, 0, lt::chain_state_bytes() * nchains, s));
-    HIP_TRY(hipMemsetAsync(b->d_count, 0, sizeof(int) * nchains, s));
+    if (ov) { // the per-record kernels' members on their stream, behind the previous run's
+      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 1, s));
+      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 2, b->side));
+      b->side_busy = true;
+    } else {
+      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 3, s));
+    }
+    HIP_TRY(hipMemsetAsync(set ? b->d_count_b : b->d_count, 0, sizeof(int) * nchains, s));
     b->pending_reset = false;
   }
   if (restart) {
     b->t0 = 0;
     b->hist_len = 0;
   }
-  HIP_TRY(lt::launch_begin(b->d_state, (int)nchains, restart ? 1 : 0, b->d_njobs, s));
+  HIP_TRY(lt::launch_begin(b->d_state, (int)nchains, restart ? 1 : 0, b->d_njobs, set, s));
   const lt_cf32 *d_iq = iq;
   if (!iq_on_device) {
     const size_t bytes = sizeof(lt_cf32) * (size_t)b->n_channels * (size_t)n_samples;
@@ -640,9 +674,10 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.flush = flush;
   R.n_channels = b->n_channels;
   R.state = b->d_state;
-  R.recs = b->d_recs;
+  R.recs = set ? b->d_recs_b : b->d_recs;
   R.rec_cap = b->rec_cap;
-  R.rec_count = b->d_count;
+  R.rec_count = set ? b->d_count_b : b->d_count;
+  R.list_slot = set;
   R.out_hf = b->d_hf;
   R.out_cap = (int)b->hf_cap;
   R.tab = b->tab;
@@ -663,8 +698,15 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   b->ev1 = b->ev[slot][3];
   b->n_runs++;
   HIP_TRY(hipEventRecord(b->ev0, s));
-  HIP_TRY(lt::launch_run(R, s));
-  HIP_TRY(hipEventRecord(b->ev1, s));
+  HIP_TRY(lt::launch_run(R, s, ov ? b->side : nullptr));
+  HIP_TRY(hipEventRecord(b->ev1, ov ? b->side : s));
+  if (ov) {
+    HIP_TRY(hipEventRecord(b->rec_done[set], b->side));
+    b->rec_done_valid[set] = true;
+    b->side_busy = true;
+  }
+  b->cur_recs = R.recs;
+  b->cur_count = R.rec_count;
   if (!restart) {
     b->t0 += n_samples;
     if (hist_new > 0) b->hist_sel ^= 1;
@@ -720,11 +762,15 @@ int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_
   if (!b->ran) return fail(LT_ERROR, "no run to collect");
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = b->last_stream;
+  if (b->side_busy) { // the last run's per-record kernels
+    HIP_TRY(hipStreamSynchronize(b->side));
+    b->side_busy = false;
+  }
   const size_t nchains = (size_t)b->n_channels * 3;
   b->h_count.resize(nchains);
   b->h_recs.resize(nchains * (size_t)b->rec_cap);
-  HIP_TRY(hipMemcpyAsync(b->h_count.data(), b->d_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(b->h_recs.data(), b->d_recs, sizeof(lt_record) * b->h_recs.size(),
+  HIP_TRY(hipMemcpyAsync(b->h_count.data(), b->cur_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(b->h_recs.data(), b->cur_recs, sizeof(lt_record) * b->h_recs.size(),
                          hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (size_t c = 0; c < nchains; ++c) {
@@ -745,12 +791,16 @@ int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, i
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = b->last_stream;
   HIP_TRY(hipStreamSynchronize(s));
+  if (b->side_busy) {
+    HIP_TRY(hipStreamSynchronize(b->side));
+    b->side_busy = false;
+  }
   // number of emitted half-frames = records with LT_F_EMITTED in the last run
   int nrec = 0;
-  HIP_TRY(hipMemcpy(&nrec, b->d_count + chain, sizeof nrec, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&nrec, b->cur_count + chain, sizeof nrec, hipMemcpyDeviceToHost));
   std::vector<lt_record> r((size_t)nrec);
   if (nrec)
-    HIP_TRY(hipMemcpy(r.data(), b->d_recs + (size_t)chain * b->rec_cap, sizeof(lt_record) * (size_t)nrec,
+    HIP_TRY(hipMemcpy(r.data(), b->cur_recs + (size_t)chain * b->rec_cap, sizeof(lt_record) * (size_t)nrec,
                       hipMemcpyDeviceToHost));
   int64_t n = 0;
   for (const lt_record &x : r)
@@ -774,6 +824,30 @@ int lt_batch_set_mode(lt_batch *b, int mode)
 }
 
 int lt_batch_get_mode(lt_batch *b) { return b ? b->mode : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
+
+int lt_batch_set_overlap(lt_batch *b, int on)
+{
+  if (!b || (on != 0 && on != 1)) return fail(LT_ERROR_INVALID_INPUTS, "overlap must be 0 or 1");
+  HIP_TRY(hipSetDevice(b->device));
+  if (on && !b->side) {
+    const size_t nchains = (size_t)b->n_channels * 3;
+    // lowest priority: the scan rounds' workgroups go first wherever both streams have work, the per-record kernels
+    // take what the resolvers and the ends of the rounds leave free
+    int prio_low = 0, prio_high = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio_low);
+    if (e == hipSuccess) e = hipMalloc(&b->d_recs_b, sizeof(lt_record) * nchains * (size_t)b->rec_cap);
+    if (e == hipSuccess) e = hipMalloc(&b->d_count_b, sizeof(int) * nchains);
+    if (e == hipSuccess) e = hipMemset(b->d_count_b, 0, sizeof(int) * nchains);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&b->rec_done[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(LT_ERROR, "lt_batch_set_overlap: %s", hipGetErrorString(e));
+    }
+  }
+  b->overlap = on;
+  return LT_OK;
+}
 
 int lt_batch_set_scan_segments(lt_batch *b, int first, int later)
 {

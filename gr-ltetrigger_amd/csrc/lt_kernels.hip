@@ -625,7 +625,7 @@ int scan_max_rounds() { return kMaxRounds; }
 int scan_counter_ints() { return 2 * (kMaxRounds + 1) + 2; } // job counters of every round + the per-record work list's
 int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + sizeof(int2)); }
 
-hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
+hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t records_stream)
 {
   const int n_chains = R.n_channels * 3;
   if (R.rec_cap <= 0 || n_chains <= 0) return hipErrorInvalidValue;
@@ -729,33 +729,41 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
   }
   if (R.ev_chain_done) (void)hipEventRecord(R.ev_chain_done, stream);
-  // ---- per-record kernels: CP length and SSS of the tracked half-frames
+  // ---- per-record kernels: CP length and SSS of the tracked half-frames.  They feed nothing but the records, so they
+  // may run on a stream of their own beside the next run's scan rounds (lt_batch_set_overlap).
   {
+    hipStream_t rs = stream;
+    if (records_stream) {
+      if (!R.ev_chain_done) return hipErrorInvalidValue;
+      hipError_t we = hipStreamWaitEvent(records_stream, R.ev_chain_done, 0);
+      if (we != hipSuccess) return we;
+      rs = records_stream;
+    }
     CpArgs c;
     c.iq = iq; c.ch_stride = R.ch_stride; c.hist = hist; c.hist_stride = R.hist_stride; c.t0 = R.t0; c.n = R.n;
     c.hist_len = R.hist_len; c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.metrics = reinterpret_cast<CpMetrics *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
     // (the work list sits behind the metrics in the same scratch buffer; its counter behind the job counters)
     c.list = reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * (size_t)n_chains * (size_t)R.rec_cap);
-    c.list_count = R.n_jobs + 2 * (kMaxRounds + 1);
+    c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
     SssArgs q;
     q.iq = iq; q.ch_stride = R.ch_stride; q.hist = hist; q.hist_stride = R.hist_stride; q.t0 = R.t0; q.n = R.n;
     q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;
     q.list = c.list; q.list_count = c.list_count;
     const dim3 per_record((unsigned)kListBlocks);
-    hipLaunchKernelGGL(lt_list_kernel, dim3((unsigned)n_chains), dim3(256), 0, stream, c);
-    hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, stream, c);
-    hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, stream, c);
-    hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, stream, c);
-    hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, stream, c);
-    hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, stream, q);
+    hipLaunchKernelGGL(lt_list_kernel, dim3((unsigned)n_chains), dim3(256), 0, rs, c);
+    hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, rs, c);
+    hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
+    hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, rs, c);
+    hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
+    hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, rs, q);
     if (R.out_hf && R.out_cap > 0) {
       if (R.rec_cap > 65535) return hipErrorInvalidValue;
       HfArgs h;
       h.iq = iq; h.ch_stride = R.ch_stride; h.hist = hist; h.hist_stride = R.hist_stride; h.t0 = R.t0; h.n = R.n;
       h.hist_len = R.hist_len; h.recs = R.recs; h.rec_cap = R.rec_cap; h.rec_count = R.rec_count;
       h.out_hf = reinterpret_cast<v2f *>(R.out_hf); h.out_cap = R.out_cap; h.tab = R.tab;
-      hipLaunchKernelGGL(lt_hf_kernel, dim3((unsigned)n_chains, (unsigned)R.rec_cap), dim3(256), 0, stream, h);
+      hipLaunchKernelGGL(lt_hf_kernel, dim3((unsigned)n_chains, (unsigned)R.rec_cap), dim3(256), 0, rs, h);
     }
   }
   // ---- history for the next chunk
@@ -768,20 +776,42 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream)
   return hipGetLastError();
 }
 
+// lt_batch_reset: the chains back to their constructor state (all zeros).  The members only the per-record kernels
+// touch (CFO ring, CP averages) are cleared separately, so that with lt_batch_set_overlap they can be cleared on the
+// stream those kernels run on, behind the previous run's.  parts: 1 = everything else, 2 = those members, 3 = all.
+__global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int parts)
+{
+  uint32_t *w = reinterpret_cast<uint32_t *>(state + blockIdx.x);
+  constexpr int n = (int)(sizeof(ChainState) / 4);
+  constexpr int i_cfo = (int)(offsetof(ChainState, cfo_i) / 4), i_norm = (int)(offsetof(ChainState, m_norm_avg) / 4);
+  constexpr int i_ext = (int)(offsetof(ChainState, m_ext_avg) / 4), i_ring = (int)(offsetof(ChainState, cfo_data) / 4);
+  static_assert(sizeof(ChainState) % 4 == 0, "ChainState is cleared word by word");
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const bool rec = i == i_cfo || i == i_norm || i == i_ext || (i >= i_ring && i < i_ring + kMovingAvgSz);
+    if (parts & (rec ? 2 : 1)) w[i] = 0u;
+  }
+}
+hipError_t launch_reset(void *state, int n_chains, int parts, hipStream_t stream)
+{
+  hipLaunchKernelGGL(lt_reset_kernel, dim3((unsigned)n_chains), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), parts);
+  return hipGetLastError();
+}
+
 // First launch of a run: the counters of its scan rounds and of its work list start at zero, and a run that is a
 // capture of its own (lt_batch_run) starts its positions at 0 again.
-__global__ void lt_begin_kernel(ChainState *state, int n_chains, int rebase, int *counters, int n_counters)
+__global__ void lt_begin_kernel(ChainState *state, int n_chains, int rebase, int *counters, int n_counters, int keep)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (rebase && i < n_chains) state[i].pos = 0;
-  if (i < n_counters) counters[i] = 0;
+  if (i < n_counters && i != keep) counters[i] = 0;
 }
-hipError_t launch_begin(void *state, int n_chains, int rebase, int *counters, hipStream_t stream)
+hipError_t launch_begin(void *state, int n_chains, int rebase, int *counters, int list_slot, hipStream_t stream)
 {
   const int n_counters = scan_counter_ints();
   const int n = n_chains > n_counters ? n_chains : n_counters;
+  const int keep = 2 * (kMaxRounds + 1) + (list_slot ? 0 : 1); // the other slot's work-list counter
   hipLaunchKernelGGL(lt_begin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), n_chains, rebase,
-                     counters, n_counters);
+                     counters, n_counters, keep);
   return hipGetLastError();
 }
 

@@ -173,6 +173,13 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
+/* Overlap (default 0): with 1, the per-record kernels of an lt_batch_run on a device buffer (CFO, CP, SSS: they feed
+ * nothing but the records) are enqueued on a stream of the batch's own and run beside the scan rounds of the next
+ * lt_batch_run; two sets of records take turns.  The run's stream then does NOT wait for them: the records are
+ * complete once lt_batch_collect (or lt_batch_get_halfframes / lt_batch_last_kernel_ms) has returned, and the sample
+ * buffer of a run must stay untouched until then.  lt_batch_push and runs from host memory are not overlapped.
+ * Same records either way. */
+int lt_batch_set_overlap(lt_batch *b, int on);
 /* The grid scan runs in rounds of windows; a chain that fires leaves the scan at the end of its round.
  * first = windows in the first round (default 2: cells present from the start of a capture fire at once),
  * later = windows in every following round, at most 128 (default 0: the chunk's windows split evenly over as few

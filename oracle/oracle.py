@@ -307,3 +307,29 @@ def decimate(x, decim):
     n = lib().orc_decimate(xp, x.size, decim, t.ctypes.data_as(C.c_void_p), t.size,
                            y.ctypes.data_as(C.c_void_p))
     return y[:n]
+
+
+def argmax_within_tolerance(x, n_id_2, recs, call, lag_other, rtol=1e-4):
+    """A peak position that differs from this oracle's at `call` of a chain's records: is the other lag's average
+    within the lag metric's tolerance (1e-4 relative, north_star) of the peak's, in the oracle's own average at
+    that call?  Replays the searches up to the call (srslte_pss_reset where tracking starts and where the score is
+    reset, lib/pss_impl.cc:119-152).  x = the channel's samples, recs = chain_run's records for n_id_2."""
+    p = Pss(n_id_2)
+    tracking = False
+    for i in range(call + 1):
+        r = recs[i]
+        if r["flags"] & 1:  # LT_F_SEARCHED
+            pos = int(r["in_pos"])
+            seg = x[pos:pos + 9600]
+            if seg.size < 9600:
+                return False
+            p.find_pss(seg)
+            if i == call:
+                a = p.avg()
+                top = float(a[int(r["peak_pos"])])
+                return abs(top - float(a[int(lag_other)])) <= rtol * abs(top)
+        now = bool(r["flags"] & 4)  # LT_F_TRACKING
+        if (now and not tracking) or (r["flags"] & 16):  # tracking starts / score reset (tracking_lost tag)
+            p.reset()
+        tracking = now
+    return False

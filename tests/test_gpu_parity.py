@@ -435,3 +435,44 @@ def test_chain_long_rounds(lt, oracle, frames_192, seed):
         got = b.collect()
         for c in range(3 * iq.shape[0]):
             assert_records_match(got[c], want[c], f"seed {seed} rounds {seg} {kw} chain {c}")
+
+
+def test_overlap_gives_the_same_records(lt, oracle, frames_192):
+    """lt_batch_set_overlap: the per-record kernels of a run beside the next run's scan rounds (second stream, two
+    sets of records).  A sequence of device runs over two alternating captures gives the records of the same sequence
+    without overlap, bit for bit -- collected after every run, collected only at the end, and across a switch back."""
+    import torch
+    dev = torch.device("cuda", 0)
+    base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
+    a, _ = siggen.scan_channels(base, 6, 60 * 9600 + 123, snr_db=12.0, cfo=True, seed0=70)
+    b2, _ = siggen.scan_channels(base, 6, 60 * 9600 + 123, snr_db=6.0, cfo=True, seed0=80)
+    bufs = [torch.from_numpy(a).to(dev), torch.from_numpy(b2).to(dev)]
+    n = a.shape[1]
+    s = torch.cuda.current_stream(dev)
+    seq = [0, 1, 0, 0, 1]
+
+    def run(overlap, collect_each, switch_at=None):
+        bt = lt.Batch(6, n)
+        bt.set_overlap(overlap)
+        out = []
+        for i, k in enumerate(seq):
+            if switch_at is not None and i == switch_at:
+                bt.set_overlap(not overlap)
+            bt.run_device(torch.view_as_real(bufs[k]).data_ptr(), n, s.cuda_stream)
+            if collect_each or i == len(seq) - 1:
+                out.append([r.copy() for r in bt.collect()])
+        return out
+
+    ref = run(False, True)
+    for got in (run(True, True), run(True, True, switch_at=2), run(False, True, switch_at=3)):
+        assert len(got) == len(ref)
+        for i in range(len(ref)):
+            for c in range(18):
+                assert got[i][c].tobytes() == ref[i][c].tobytes(), f"run {i} chain {c}"
+    last = run(True, False)
+    for c in range(18):
+        assert last[0][c].tobytes() == ref[-1][c].tobytes(), f"chain {c} (collected at the end only)"
+    # and the first run is the oracle's
+    want = oracle.batch_run(a, nthreads=8)
+    for c in range(18):
+        assert_records_match(ref[0][c], want[c], f"chain {c}")

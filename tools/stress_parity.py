@@ -45,28 +45,8 @@ def first_difference(got, want):
 
 
 def near_tie(O, x, n_id_2, want, call, lag_gpu):
-    """A peak position that differs from the oracle's: are the two lags' averages within the lag metric's
-    tolerance (1e-4 relative) in the oracle's own average at that call?  Replays the oracle's searches up to the
-    call (srslte_pss_reset where tracking starts and where the score is reset, lib/pss_impl.cc:119-152)."""
-    p = O.Pss(n_id_2)
-    tracking = False
-    for i in range(call + 1):
-        r = want[i]
-        if r["flags"] & 1:  # LT_F_SEARCHED
-            pos = int(r["in_pos"])
-            seg = x[pos:pos + 9600]
-            if seg.size < 9600:
-                return False
-            p.find_pss(seg)
-            if i == call:
-                a = p.avg()
-                top = float(a[int(r["peak_pos"])])
-                return abs(top - float(a[int(lag_gpu)])) <= 1e-4 * abs(top)
-        now = bool(r["flags"] & 4)  # LT_F_TRACKING
-        if (now and not tracking) or (r["flags"] & 16):  # tracking starts / score reset (tracking_lost tag)
-            p.reset()
-        tracking = now
-    return False
+    """(oracle.argmax_within_tolerance)"""
+    return O.argmax_within_tolerance(x, n_id_2, want, call, lag_gpu)
 
 
 def main():
