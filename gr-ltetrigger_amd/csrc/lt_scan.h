@@ -353,9 +353,9 @@ __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)
 // diagnostics build: the same with shader-clock stamps between the stages (tools/scan_bench.hip)
 __device__ __forceinline__ void strip_root_update_prof(int s, int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
                                                        const fft::c32 *tw2, fft::c32 *e,
-                                                       ema_t &ema, unsigned long long (&pr)[8], unsigned long long &tp)
+                                                       ema_t &ema, unsigned *pr, unsigned &tp)
 {
-#define LT_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; __builtin_amdgcn_sched_barrier(0); }
+#define LT_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&pr[i], t_ - tp); tp = t_; __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
   for (int R = 0; R < 16; ++R) v[R] = fft::cmulw<false>(v[R], spec[R]);
   LT_PS(2) // filter spectrum

@@ -119,6 +119,9 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   __shared__ fft::c32 TW1[16 * 64];
   __shared__ fft::c32 TW2[16 * 4];
   __shared__ int sync_ready[kScanGroups][3], sync_taken[kScanGroups][3];
+#ifdef LT_SCAN_PROF
+  __shared__ unsigned PROF[kScanWaves][8]; // shader-clock ticks per phase and wave (in LDS: the kernel has no scalar registers to spare)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroups b, b + 8, b + 16, b + 24 (one XCD under round-robin dispatch) share a job: its strips overlap
@@ -149,6 +152,9 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
   for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
   if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
   if (tid < kScanGroups * 3) (&sync_ready[0][0])[tid] = (&sync_taken[0][0])[tid] = 0;
+#ifdef LT_SCAN_PROF
+  if (tid < kScanWaves * 8) (&PROF[0][0])[tid] = 0u;
+#endif
   __syncthreads(); // tables in place: the only workgroup barrier
   fft::c32 *e = E + w * fft::kScratchW;
 
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     int held_roots0 = 0, held_roots1 = 0, held_need0 = 0, held_need1 = 0;
     int h = 0;
 #ifdef LT_SCAN_PROF
-    unsigned long long pr[8] = {0}, tp = __builtin_amdgcn_s_memtime();
-#define LT_FSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; __builtin_amdgcn_sched_barrier(0); }
+    unsigned tp = (unsigned)__builtin_amdgcn_s_memtime();
+#define LT_FSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&PROF[w][i], t_ - tp); tp = t_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define LT_FSTAMP(i)
 #endif
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     }
 #ifdef LT_SCAN_PROF
     if (a.prof && blockIdx.x == 8 && lane == 0) {
-      for (int i = 0; i < 8; ++i) a.prof[w * 8 + i] = pr[i];
+      for (int i = 0; i < 8; ++i) a.prof[w * 8 + i] = PROF[w][i];
       unsigned id;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
       a.prof[96 + w] = id;
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     }
     StripPartial *parts = a.parts + (int64_t)chain * kScanMaxRound * kStrips + strip;
 #ifdef LT_SCAN_PROF
-    unsigned long long pr[8] = {0}, tp = __builtin_amdgcn_s_memtime();
-#define LT_PSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[i] += t_ - tp; tp = t_; }
+    unsigned tp = (unsigned)__builtin_amdgcn_s_memtime();
+#define LT_PSTAMP(i) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&PROF[w][i], t_ - tp); tp = t_; }
 #else
 #define LT_PSTAMP(i)
 #endif
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
         for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
       }
 #ifdef LT_SCAN_PROF
-      strip_root_update_prof(strip, ln, x, spec, tw, TW2, e, ema, pr, tp);
+      strip_root_update_prof(strip, ln, x, spec, tw, TW2, e, ema, PROF[w], tp);
 #else
       strip_root_update(strip, ln, x, spec, tw, TW2, e, ema);
 #endif
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
     }
 #ifdef LT_SCAN_PROF
     if (a.prof && blockIdx.x == 8 && lane == 0) {
-      for (int i = 0; i < 8; ++i) a.prof[w * 8 + i] = pr[i];
+      for (int i = 0; i < 8; ++i) a.prof[w * 8 + i] = PROF[w][i];
       unsigned id;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
       a.prof[96 + w] = id;

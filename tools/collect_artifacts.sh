@@ -1,9 +1,9 @@
 set -x
-mkdir -p gpurun_out/final
+rm -rf gpurun_out/final && mkdir -p gpurun_out/final
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/final/r02_bench.json.log 2> gpurun_out/final/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_full -- python3 bench.py > gpurun_out/final/r02_bench_under_rocprof.json.log 2> gpurun_out/final/bench_prof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_path -- python3 bench.py --steps 10 --warmup 3 --no-end-to-end --no-config2 --no-cpu-baseline > gpurun_out/final/bench_path.json 2> gpurun_out/final/bench_path.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_path -- python3 bench.py --steps 10 --warmup 3 --no-end-to-end --no-config2 --no-cpu-baseline --no-overlap-leg > gpurun_out/final/bench_path.json 2> gpurun_out/final/bench_path.err
 python tools/timeline.py gpurun_out/final/prof_path > gpurun_out/final/r02_timeline.txt
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/final/prof_overlap -- python3 bench.py --overlap --steps 10 --warmup 3 --no-end-to-end --no-config2 --no-cpu-baseline > gpurun_out/final/bench_overlap.json 2> gpurun_out/final/bench_overlap.err
 python tools/timeline2.py gpurun_out/final/prof_overlap 3 > gpurun_out/final/r02_timeline_overlap.txt

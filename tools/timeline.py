@@ -4,7 +4,8 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)  # (the newest, if old runs were merged into the directory)
 rows = [r for r in csv.DictReader(open(f)) if "lt::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "lt_begin_kernel" in r["Kernel_Name"]]

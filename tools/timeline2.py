@@ -5,12 +5,14 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)  # (the newest, if old runs were merged into the directory)
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = [r for r in csv.DictReader(open(f)) if "lt::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 begins = [i for i, r in enumerate(rows) if "lt_begin_kernel" in r["Kernel_Name"]]
-i0, i1 = begins[-back - 1], begins[-back + 1] if back > 1 else len(rows)
+i0 = begins[-back - 1]
+i1 = begins[-back + 1] if back > 1 else len(rows)
 t0 = int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i1]:
     name = r["Kernel_Name"].split("(")[0].replace("lt::", "")
