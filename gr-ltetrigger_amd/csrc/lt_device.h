@@ -48,7 +48,8 @@ struct ChainState {
   // ---- the exponential average and how the grid scan hands it on (lt_scan_kernels.h).  avg[ema_sel] is a valid
   // state of conv_output_avg; the chain's current average is that state run through the pre_n windows
   // pre_pos + k * pre_stride * 9600 (windows of a scan round whose tail the chain did not follow), or all
-  // zeros when ema_zero is set (srslte_pss_reset).  A scan round writes into the other two buffers.
+  // zeros when ema_zero is set (1: srslte_pss_reset; 2: lt_batch_reset, which leaves the 117 KB of buffers alone).
+  // A scan round writes into the other two buffers.
   int32_t ema_sel;
   int32_t ema_zero;
   int32_t pre_n;

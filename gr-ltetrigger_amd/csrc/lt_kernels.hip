@@ -776,19 +776,21 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
   return hipGetLastError();
 }
 
-// lt_batch_reset: the chains back to their constructor state (all zeros).  The members only the per-record kernels
+// lt_batch_reset: the chains back to their constructor state.  The members only the per-record kernels
 // touch (CFO ring, CP averages) are cleared separately, so that with lt_batch_set_overlap they can be cleared on the
 // stream those kernels run on, behind the previous run's.  parts: 1 = everything else, 2 = those members, 3 = all.
 __global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int parts)
 {
   uint32_t *w = reinterpret_cast<uint32_t *>(state + blockIdx.x);
-  constexpr int n = (int)(sizeof(ChainState) / 4);
+  // everything in front of the three average buffers; those are not cleared but declared zero (ema_zero = 2)
+  constexpr int n = (int)(offsetof(ChainState, avg) / 4);
   constexpr int i_cfo = (int)(offsetof(ChainState, cfo_i) / 4), i_norm = (int)(offsetof(ChainState, m_norm_avg) / 4);
   constexpr int i_ext = (int)(offsetof(ChainState, m_ext_avg) / 4), i_ring = (int)(offsetof(ChainState, cfo_data) / 4);
-  static_assert(sizeof(ChainState) % 4 == 0, "ChainState is cleared word by word");
+  constexpr int i_zero = (int)(offsetof(ChainState, ema_zero) / 4);
+  static_assert(offsetof(ChainState, avg) % 4 == 0, "ChainState is cleared word by word");
   for (int i = threadIdx.x; i < n; i += 256) {
     const bool rec = i == i_cfo || i == i_norm || i == i_ext || (i >= i_ring && i < i_ring + kMovingAvgSz);
-    if (parts & (rec ? 2 : 1)) w[i] = 0u;
+    if (parts & (rec ? 2 : 1)) w[i] = i == i_zero ? 2u : 0u;
   }
 }
 hipError_t launch_reset(void *state, int n_chains, int parts, hipStream_t stream)

@@ -93,6 +93,9 @@ constexpr int kScanWaves = 12;
 constexpr int kScanThreads = 64 * kScanWaves;
 constexpr int kScanGroups = 3;              // strips per workgroup
 constexpr int kScanWgPerJob = kStrips / kScanGroups;
+#ifndef LT_POLL_SLEEP
+#define LT_POLL_SLEEP 1 // s_sleep units (64 clocks) between two looks at a hand-over counter
+#endif
 constexpr int kScanMaxRound = 128;           // windows per job and round at most (one resolver lane each)
 
 struct ScanArgs {
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         if ((hr >> r) & 1)
-          while (__hip_atomic_load(&sync_taken[g][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hn) __builtin_amdgcn_s_sleep(1);
+          while (__hip_atomic_load(&sync_taken[g][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hn) __builtin_amdgcn_s_sleep(LT_POLL_SLEEP);
       LT_FSTAMP(2) // waiting for the buffer
       LT_LDS_ORDER;
       fft::fft1024w_stageB<false>(ln, x, TW2, e, OUT[g][h & 1]);
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
       __builtin_amdgcn_sched_barrier(0);
       const int hk = k + (k < n1 ? k : n1) + (k < n2 ? k : n2) + (my_seq >= 1) + (my_seq >= 2 && k < n1);
       const fft::c32 *e_fwd = OUT[g][hk & 1];
-      while (__hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(LT_POLL_SLEEP);
       LT_LDS_ORDER;
       LT_PSTAMP(0) // waiting for the forward wave
       fft::fft1024w_stageC<false>(ln, x, e_fwd); // x = the block's spectrum
@@ -354,9 +357,9 @@ struct PlanArgs {
 // the job of channel c for the next round
 __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
 {
-  int n[3], stride[3], n_c[3];
+  int n[3], stride[3], n_c[3], fresh[3];
   int64_t first[3], pos_c[3];
-  bool plain[3]; // the average is avg[ema_sel] as it stands, and the windows end with the round
+  bool plain[3]; // the average is a stored state as it stands (avg[ema_sel], or the zeros a stream starts from), and the windows end with the round
   const int64_t limit = a.t1 - (a.flush ? kHalfFrame : a.call_reach); // last position a call may start at
   for (int r = 0; r < 3; ++r) {
     ChainState *st = a.state + c * 3 + r;
@@ -372,7 +375,8 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     stride[r] = st->is_tracking ? a.track_every + 1 : 1;
     // the calls before the next search emit without searching: timer of them (lib/pss_impl.cc:170-172)
     first[r] = st->pos + (st->is_tracking ? (int64_t)st->timer * kHalfFrame : 0);
-    plain[r] = st->pre_n == 0 && !st->ema_zero;
+    fresh[r] = st->ema_zero == 2; // (lt_batch_reset: zeros that are no srslte_pss_reset)
+    plain[r] = st->pre_n == 0 && (st->ema_zero == 0 || fresh[r]);
     if (!a.enable || st->run_done || st->need_chain || st->tracking_lost) continue;
     if (first[r] > limit) continue;
     int64_t m = (limit - first[r]) / ((int64_t)stride[r] * kHalfFrame) + 1;
@@ -388,8 +392,8 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     // to start tracking track_after windows later, so it gets no more than that.
     if (!st->is_tracking && st->pre_n > 0 && m > 2) m = 2;
     // ... and, if it does, to start tracking track_after windows later: no more than those here.  (ema_zero is set
-    // by a reset only: a stream starts from avg[0] = zeros, not from the flag.)
-    const bool after_reset = !st->is_tracking && st->score == 0 && st->ema_zero;
+    // = 1 by srslte_pss_reset only: a stream starts from avg[0] = zeros or, after lt_batch_reset, from the value 2.)
+    const bool after_reset = !st->is_tracking && st->score == 0 && st->ema_zero == 1;
     if (after_reset && m > a.track_after) m = a.track_after;
     if (m > kScanMaxRound - st->pre_n) m = kScanMaxRound - st->pre_n;
     n[r] = m > 0 ? (int)m : 0;
@@ -424,7 +428,7 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     lead[r] = n[r] > 0 ? r : -1;
 #pragma unroll
     for (int p = 0; p < r; ++p)
-      if (lead[r] == r && lead[p] == p && plain[p] && plain[r] && first[p] == first[r] && stride[p] == stride[r]) lead[r] = p;
+      if (lead[r] == r && lead[p] == p && plain[p] && plain[r] && fresh[p] == fresh[r] && first[p] == first[r] && stride[p] == stride[r]) lead[r] = p;
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
