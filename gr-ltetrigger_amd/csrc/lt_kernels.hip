@@ -1,10 +1,13 @@
 // gfx950 kernels of the LTE cell-search hot path.
 //
 // lt_batch_run / lt_batch_push:
-//   lt_plan_kernel, lt_scan_kernel, lt_resolve_kernel (lt_scan_kernels.h) -- the searches of all idle chains, strip-wise,
-//                         exponential averages in registers, one forward transform per block shared by the three roots.
-//   lt_chain_kernel (lt_chain_kernel.h) -- one workgroup per chain that fired (or that the scan does not serve):
-//                         pss_impl::general_work call by call (lib/pss_impl.cc:155-223), CFO ring; one lt_record per call.
+//   lt_begin_kernel / lt_reset_kernel -- run start (counters, positions) and lt_batch_reset.
+//   lt_plan_kernel, lt_scan_kernel, lt_resolve_kernel (lt_scan_kernels.h) -- the searches of all chains in rounds,
+//                         strip-wise, exponential averages in registers, one forward transform per block shared by the
+//                         chains of a window sequence; pss_impl::general_work (lib/pss_impl.cc:155-223) on the results.
+//   lt_chain_kernel (lt_chain_kernel.h) -- one workgroup per chain: general_work call by call for whatever the rounds
+//                         leave over (and for every chain in mode 0); one lt_record per call.
+//   lt_list_kernel     -- work list of the tracked half-frames for the per-record kernels:
 //   lt_cfo_kernel, lt_cfo_ring_kernel -- CFO estimate and mean_cfo() of the tracked half-frames (lib/pss_impl.cc:199-204),
 //   lt_cp_kernel, lt_cp_scan_kernel, lt_sss_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) on them, lt_hf_kernel -- the
 //                         pss block's output stream (optional capture): all per record, afterwards (they feed records only).

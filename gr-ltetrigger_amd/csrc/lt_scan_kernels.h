@@ -1,27 +1,27 @@
-// Grid scan: srslte_pss_find_pss (lib/pss_impl.cc:165-167) of every idle chain, window after window, with
-// the exponential average held in registers and nothing but 32-byte partial results per (window, strip)
-// written back.  See lt_scan.h for the strip geometry.
+// Scan rounds: srslte_pss_find_pss (lib/pss_impl.cc:165-167) of every chain, window after window, with the
+// exponential average held in registers and nothing but 32-byte partial results per (window, strip) written
+// back.  See lt_scan.h for the strip geometry.
 //
 // Where a chain will search next is known in advance as long as nothing changes its timing: an idle chain (not
 // tracking, score 0) searches every 9600-sample window, misses and moves on by exactly 9600 samples
-// (lib/pss_impl.cc:163-182, 217); a chain that builds its score or tracks keeps hitting at peak_pos 960 and
-// searches every window, or every (track_every + 1)-th one (lib/pss_impl.cc:163-172, 185-195).  That is what
-// nearly all chains do nearly all the time, and the search is where the arithmetic is.  The work runs in rounds:
-// lt_plan_kernel groups the chains of a channel that will search the same windows into a job, lt_scan_kernel
-// runs the next windows of every job speculatively, and lt_resolve_kernel executes general_work call by call on
-// the results, for as long as the chain stays on the windows that were scanned.  A chain that leaves them -- a
-// first hit re-aligns it, tracking starts or is lost -- joins a new job in the next round; its average is carried
-// over exactly (ChainState: a valid state + the windows to run it through again, or all zeros after
-// srslte_pss_reset).  A window the strips cannot resolve hands the chain to the per-chain kernel (lt_chain_kernel.h).
+// (lib/pss_impl.cc:163-182, 217); a chain that builds its score keeps hitting at peak_pos 960 and searches every
+// window, a tracked one every (track_every + 1)-th (lib/pss_impl.cc:163-172, 185-195).  That is what nearly all
+// chains do nearly all the time, and the search is where the arithmetic is.  The work runs in rounds:
+// lt_plan_kernel puts the chains of a channel into one job -- up to three window sequences, one per set of chains
+// that will search the same windows --, lt_scan_kernel runs the next windows of every sequence speculatively, and
+// lt_resolve_kernel executes general_work call by call on the results, for as long as the chain stays on the
+// windows that were scanned.  A chain that leaves them -- a hit re-aligns it, tracking is lost -- gets a sequence
+// of its own in the next round; its average is carried over exactly (ChainState: a valid state + the windows to
+// run it through again, or all zeros after srslte_pss_reset).  A window the strips cannot resolve hands the chain
+// to the per-chain kernel (lt_chain_kernel.h).
 //
-// Work decomposition.  A *job* is a capture channel together with the idle chains (roots) of it that share
-// one window alignment -- normally all three.  A job's 12 strips go to four workgroups of three *groups*;
-// a group is four waves that own one strip for good: a forward wave, which fetches the strip's 1024 samples of
-// every window and transforms them once, and one wave per root, which multiplies that spectrum by its root's
-// filter spectrum, transforms back and keeps its root's average.  The hand-over costs no LDS of its own: the
-// forward wave stops after the second exchange of its transform, and each root wave runs the last radix-4 stage
-// itself, straight out of the forward wave's exchange area.
-//   workgroup = 12 waves = 3 per SIMD; LDS: 12 exchange areas (102 KB) + filter spectra (24 KB) + twiddles (17 KB)
+// Work decomposition.  A job's 12 strips go to four workgroups of three *groups*; a group is four waves that own
+// one strip for the whole round: a forward wave, which fetches the strip's 1024 samples of every window of every
+// sequence and runs the first two stages of their transform, and one wave per root, which runs the last stage out
+// of the hand-over buffer, multiplies the spectrum by its root's filter spectrum (held in registers), transforms
+// back, keeps its root's average and reduces it to the strip's partial result.
+//   workgroup = 12 waves = 3 per SIMD; LDS: 12 exchange areas (102 KB) + 6 hand-over buffers (49 KB) + twiddles
+//   (8.5 KB) = 163 160 of 163 840 bytes
 #pragma once
 #include "lt_scan.h"
 
