@@ -720,6 +720,24 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       }
     }
   }
+  if (getenv("LT_DEBUG_JOBS")) { // diagnostics: what the rounds leave to the per-chain kernel
+    (void)hipStreamSynchronize(stream);
+    std::vector<char> hs((size_t)n_chains * sizeof(ChainState));
+    (void)hipMemcpy(hs.data(), state, hs.size(), hipMemcpyDeviceToHost);
+    const int64_t limit = t1 - (R.flush ? kHalfFrame : kCallReach);
+    int need = 0, done = 0, behind = 0;
+    long windows_left = 0;
+    for (int c = 0; c < n_chains; ++c) {
+      const ChainState *st = reinterpret_cast<const ChainState *>(hs.data() + (size_t)c * sizeof(ChainState));
+      need += st->need_chain != 0;
+      done += st->run_done != 0;
+      if (!st->run_done && st->pos <= limit) {
+        behind++;
+        windows_left += (long)((limit - st->pos) / kHalfFrame + 1);
+      }
+    }
+    fprintf(stderr, "after the rounds: %d chains need the exact path, %d stopped, %d not through (%ld windows left)\n", need, done, behind, windows_left);
+  }
   if (R.ev_scan_done) (void)hipEventRecord(R.ev_scan_done, stream);
   // ---- per-chain kernel
   {

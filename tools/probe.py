@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mode", default="mix", choices=["noise", "clean", "mix", "decim"])
     ap.add_argument("--threshold", type=float, default=4.0)
+    ap.add_argument("--snr-db", type=float, default=20.0, help="mode mix: SNR of the channels that carry a cell")
     ap.add_argument("--exec-mode", type=int, default=1, help="lt_batch_set_mode: 1 = grid scan + per-chain kernel, 0 = per-chain kernel only")
     ap.add_argument("--scan-segments", default="", help="first,later windows per scan round")
     args = ap.parse_args()
@@ -51,7 +52,7 @@ def main():
         for c in range(7, args.channels, 8):  # make every channel carry a cell
             iq[c] = iq[c - 1]
     else:
-        iq, _ = bench.make_channels(torch, frames, args.channels, n, 0, 20.0, dev)
+        iq, _ = bench.make_channels(torch, frames, args.channels, n, 0, args.snr_db, dev)
     iqr = torch.view_as_real(iq).contiguous()
     torch.cuda.synchronize()
     b = lt.Batch(args.channels, n, psr_threshold=args.threshold)
