@@ -476,3 +476,28 @@ def test_overlap_gives_the_same_records(lt, oracle, frames_192):
     want = oracle.batch_run(a, nthreads=8)
     for c in range(18):
         assert_records_match(ref[0][c], want[c], f"chain {c}")
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_reset_is_a_fresh_batch(lt, oracle, frames_192, mode):
+    """lt_batch_reset declares the averages zero instead of clearing them (and clears the rest of the state): a
+    batch that has run on one capture, is reset and runs on another gives the records of a fresh batch, bit for bit."""
+    base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
+    a, _ = siggen.scan_channels(base, 5, 70 * 9600 + 17, snr_db=10.0, cfo=True, seed0=90)
+    b2, _ = siggen.scan_channels(base, 5, 70 * 9600 + 17, snr_db=3.0, cfo=True, seed0=95)
+    fresh = lt.Batch(5, a.shape[1])
+    fresh.set_mode(mode)
+    fresh.run_host(b2)
+    want = [r.copy() for r in fresh.collect()]
+    used = lt.Batch(5, a.shape[1])
+    used.set_mode(mode)
+    used.run_host(a)
+    used.collect()
+    used.reset()
+    used.run_host(b2)
+    got = used.collect()
+    for c in range(15):
+        assert got[c].tobytes() == want[c].tobytes(), f"chain {c}"
+    ref = oracle.batch_run(b2, nthreads=8)
+    for c in range(15):
+        assert_records_match(want[c], ref[c], f"chain {c}")
