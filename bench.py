@@ -374,11 +374,12 @@ def main():
         }
         if overlap_leg is not None:
             out["overlapped"] = overlap_leg
-        if not args.no_end_to_end:
+        # the side measurements run at N = 1 only (rank 0 would keep the other ranks waiting at the last barrier)
+        if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(torch, lt, iq, n_ch, n, local_rank)
-        if not args.no_config2:
+        if world == 1 and not args.no_config2:
             out["config2"] = config2(torch, lt, dev, local_rank)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lt, iq, recs, min(args.cpu_channels, n_ch), value / world, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
