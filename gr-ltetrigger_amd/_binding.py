@@ -44,7 +44,7 @@ EXPORTS = [
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
     "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms", "lt_batch_push",
-    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap",
+    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_set_scan_groups",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
 
@@ -124,6 +124,7 @@ def lib():
     L.lt_batch_get_mode.argtypes = [vp]
     L.lt_batch_set_scan_segments.argtypes = [vp, i32, i32]
     L.lt_batch_set_overlap.argtypes = [vp, i32]
+    L.lt_batch_set_scan_groups.argtypes = [vp, i32]
     L.lt_batch_collect.argtypes = [vp, vp, i64, vp]
     L.lt_batch_record_capacity.argtypes = [i64]
     L.lt_batch_record_capacity.restype = i64
@@ -329,6 +330,10 @@ class Batch:
 
     def mode(self):
         return int(lib().lt_batch_get_mode(self._h))
+
+    def set_scan_groups(self, strips_per_workgroup):
+        """Shape of the scan's workgroups (lt_batch_set_scan_groups): 0 = automatic, 1, 2 or 3 strips each."""
+        _check(lib().lt_batch_set_scan_groups(self._h, int(strips_per_workgroup)), "lt_batch_set_scan_groups")
 
     def set_overlap(self, on):
         """Per-record kernels of a device run beside the next run's scan rounds (lt_batch_set_overlap)."""

@@ -158,6 +158,8 @@ struct lt_batch {
   int64_t t0 = 0;            // absolute stream position of the next chunk
   int mode = 1;              // 0 per-chain kernel only, 1 grid scan + per-chain kernel
   int seg_first = 2, seg_len = 0;
+  int scan_groups = 0;       // strips per scan workgroup (0: chosen per run from the channel count)
+  int n_cus = 0;
   bool pending_reset = false; // lt_batch_reset: applied on the stream of the next run, in front of it
   // events of the last kPhaseRing runs: [run % kPhaseRing][0..3] = start, scan done, per-chain kernel done, end
   static constexpr int kPhaseRing = 8;
@@ -524,6 +526,11 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   b->max_samples = max_samples;
   b->params = *params;
   b->rec_cap = (int)lt_batch_record_capacity(max_samples);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->n_cus = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+  }
   b->hist_cap = history_capacity();
   rc = get_tables(device, &b->tab);
   if (rc) { delete b; return rc; }
@@ -690,6 +697,8 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.parts = b->d_parts;
   R.seg_first = b->seg_first;
   R.seg_len = b->seg_len;
+  R.scan_groups = b->scan_groups;
+  R.n_cus = b->n_cus;
   R.cp_scratch = b->d_cp;
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
   R.ev_scan_done = b->ev[slot][1];
@@ -824,6 +833,14 @@ int lt_batch_set_mode(lt_batch *b, int mode)
 }
 
 int lt_batch_get_mode(lt_batch *b) { return b ? b->mode : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
+
+int lt_batch_set_scan_groups(lt_batch *b, int strips_per_workgroup)
+{
+  if (!b || strips_per_workgroup < 0 || strips_per_workgroup > 3)
+    return fail(LT_ERROR_INVALID_INPUTS, "strips per scan workgroup: 0 (automatic), 1, 2 or 3");
+  b->scan_groups = strips_per_workgroup;
+  return LT_OK;
+}
 
 int lt_batch_set_overlap(lt_batch *b, int on)
 {

@@ -671,8 +671,29 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
     if (rounds > kMaxRounds) rounds = kMaxRounds;
     // (the counters behind R.n_jobs are zero: launch_begin)
-    // one job per channel; long and short jobs each start on a fresh group of 8 workgroups
-    const int grid = (((R.n_channels + 7) / 8) * 8 + 8) * kScanWgPerJob;
+    // Strips per workgroup: what fills the chip's CUs in the fewest turns at the cost per window measured for each
+    // shape (tools/scan_bench.hip: 3.0 / 3.5 / 4.7 us per window of a three-root sequence with 1 / 2 / 3 strips per
+    // workgroup); RunLaunch::scan_groups overrides.
+    int G = R.scan_groups;
+    if (G < 1 || G > 3) {
+      // us per window of a three-root sequence (tools/scan_bench.hip): one strip per workgroup 2.3 (one workgroup per
+      // CU) or 3.4 (two: 60 KB of LDS each), two strips 3.3, three strips 4.7; a shape's workgroups go through the
+      // chip in turns of n_cus (x 2 for one strip)
+      const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
+      double best = 0.0;
+      for (int g = 1; g <= 3; ++g) {
+        const int wgs = R.n_channels * scan_wg_per_job(g);
+        double cost;
+        if (g == 1) cost = wgs <= n_cus ? 2.3 : (double)((wgs + 2 * n_cus - 1) / (2 * n_cus)) * 3.4;
+        else cost = (double)((wgs + n_cus - 1) / n_cus) * (g == 2 ? 3.3 : 4.7);
+        if (g == 1 || cost < best - 1e-9) {
+          best = cost;
+          G = g;
+        }
+      }
+    }
+    // one job per channel at most: enough workgroups for all their parts, a multiple of the 8 XCDs
+    const int grid = ((R.n_channels * scan_wg_per_job(G) + 7) / 8) * 8;
     p.first_round = 1;
     p.round_windows = seg_first;
     p.jobs = jobs2[0];
@@ -688,7 +709,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       q.next.round_windows = seg_len;
       q.next.jobs = jobs2[(r + 1) & 1];
       q.next.n_jobs = R.n_jobs + 2 * (r + 1);
-      hipLaunchKernelGGL(lt_scan_kernel, dim3(grid), dim3(kScanThreads), 0, stream, s);
+      if (G == 1) hipLaunchKernelGGL(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
+      else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
+      else hipLaunchKernelGGL(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
       hipLaunchKernelGGL(lt_resolve_kernel, dim3(R.n_channels), dim3(192), 0, stream, q);
       if (getenv("LT_DEBUG_JOBS")) { // diagnostics: the jobs of this round
         (void)hipStreamSynchronize(stream);

@@ -40,6 +40,8 @@ struct RunLaunch {
   void *parts = nullptr;      // device, scan_parts_bytes_per_chain() per chain
   int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
   int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
+  int scan_groups = 0;        // strips per scan workgroup: 1, 2 or 3; 0 = chosen from n_channels and n_cus
+  int n_cus = 0;              // compute units of the device (0: 256)
   int extra_rounds = 2;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the work list
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel

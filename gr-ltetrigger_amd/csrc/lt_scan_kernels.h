@@ -89,10 +89,12 @@ __device__ __forceinline__ int64_t seq_window_pos(const ScanSeq &q, int k)
   return q.pos_c + (int64_t)(k - q.n_b) * q.stride_c * kHalfFrame;
 }
 
-constexpr int kScanWaves = 12;
-constexpr int kScanThreads = 64 * kScanWaves;
-constexpr int kScanGroups = 3;              // strips per workgroup
-constexpr int kScanWgPerJob = kStrips / kScanGroups;
+// A workgroup carries G strips (G groups of four waves).  G = 3 fills the chip with 64 channels (4 workgroups per
+// channel, 12 waves per CU: one root wave per SIMD sits in a third slot and is slower for it); with
+// fewer channels more, smaller workgroups put more CUs on a channel and leave no SIMD with three waves.
+constexpr int scan_waves(int G) { return 4 * G; }
+constexpr int scan_threads(int G) { return 64 * scan_waves(G); }
+constexpr int scan_wg_per_job(int G) { return kStrips / G; }
 #ifndef LT_POLL_SLEEP
 #define LT_POLL_SLEEP 1 // s_sleep units (64 clocks) between two looks at a hand-over counter
 #endif
@@ -113,8 +115,10 @@ struct ScanArgs {
   unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
 };
 
-__global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
+template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups)) void lt_scan_kernel(ScanArgs a)
 {
+  constexpr int kScanWaves = scan_waves(kScanGroups), kScanThreads = scan_threads(kScanGroups), kScanWgPerJob = scan_wg_per_job(kScanGroups);
+  static_assert(kStrips % kScanGroups == 0, "a job's strips divide evenly among its workgroups");
   __shared__ v2f E[kScanWaves * fft::kScratchW]; // one exchange area per wave
   // a forward wave leaves its blocks (two transform stages done) here for the group's root waves, in turn: while
   // they read one, it fills the other
@@ -127,20 +131,20 @@ __global__ __launch_bounds__(kScanThreads) void lt_scan_kernel(ScanArgs a)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // workgroups b, b + 8, b + 16, b + 24 (one XCD under round-robin dispatch) share a job: its strips overlap
-  // by 213 samples, so the second read of those comes from that XCD's L2
+  // Workgroup -> (job, part).  Workgroups are dispatched to the 8 XCDs in turn (b & 7), and the workgroups of a job
+  // should meet on one XCD: their strips overlap by 213 samples, the second read of those then comes from that XCD's
+  // L2.  All (job, part) pairs in job order -- long jobs first: they sit at the front of the job array, the short
+  // ones at its back -- are cut into 8 equal runs, one per XCD: every XCD gets the same number of workgroups
+  // whatever the number of jobs, and at most 7 jobs are split between two XCDs.
   const int b = blockIdx.x;
-  const int slot = b >> 3;
-  const int quarter = slot % kScanWgPerJob;
-  // long jobs first (they sit at the front of the job array, the short ones at its back): the workgroups of a launch
-  // start in index order, and a long job that starts late ends late
-  int job_i = (slot / kScanWgPerJob) * 8 + (b & 7);
   const int n_front = a.n_jobs[0], n_back = a.n_jobs[1];
-  if (job_i >= n_front) {
-    job_i -= (n_front + 7) / 8 * 8; // (the back jobs start on a fresh group of 8 workgroups: XCD pairing as above)
-    if (job_i < 0 || job_i >= n_back) return;
-    job_i = a.jobs_cap - 1 - job_i;
-  }
+  const int n_parts = (n_front + n_back) * kScanWgPerJob;
+  const int per_xcd = (n_parts + 7) >> 3;
+  const int part_i = (b & 7) * per_xcd + (b >> 3);
+  if ((b >> 3) >= per_xcd || part_i >= n_parts) return;
+  const int quarter = part_i % kScanWgPerJob;
+  int job_i = part_i / kScanWgPerJob;
+  if (job_i >= n_front) job_i = a.jobs_cap - 1 - (job_i - n_front);
   const ScanJob *jp = a.jobs + job_i; // (read piecewise: a local copy indexed by sequence would live in scratch)
   const int n_seq = uniform_i32(jp->n_seq), channel = uniform_i32(jp->channel);
   if (n_seq <= 0) return;

@@ -185,6 +185,10 @@ int lt_batch_set_overlap(lt_batch *b, int on);
  * later = windows in every following round, at most 128 (default 0: the chunk's windows split evenly over as few
  * rounds as they need). */
 int lt_batch_set_scan_segments(lt_batch *b, int first, int later);
+/* Shape of the scan's workgroups: 1, 2 or 3 of a window's 12 strips per workgroup (12, 6 or 4 workgroups per channel).
+ * 0 (default) chooses per run from the channel count and the device's CU count: three strips fill an MI355X with 64
+ * channels, fewer strips put more CUs on a channel when there are fewer channels.  Timing only, never a record. */
+int lt_batch_set_scan_groups(lt_batch *b, int strips_per_workgroup);
 /* downlink_trigger_c.set_psr_threshold fan-out (python/downlink_trigger_c.py:63-69) */
 int lt_batch_set_psr_threshold(lt_batch *b, float threshold);
 /* Run every chain over iq = [n_channels][n_samples] cf32 (channel-major, contiguous), a capture of its own:

@@ -32,7 +32,9 @@ def test_no_kernel_uses_scratch(resources):
 
 
 def test_scan_kernel_shape(resources):
-    scan = [v for k, v in resources.items() if "lt_scan_kernel" in k]
-    assert len(scan) == 1
-    assert scan[0]["vgprs"] <= 168, "12 waves per workgroup = 3 per SIMD: 168 VGPRs at most"
-    assert scan[0]["lds"] <= 160 * 1024, "a workgroup's LDS on gfx950"
+    scan = {k: v for k, v in resources.items() if "lt_scan_kernel" in k}
+    assert len(scan) == 3, "one instance per number of strips per workgroup (1, 2, 3)"
+    for k, v in scan.items():
+        assert v["vgprs"] <= 168, f"{k}: at most three waves of a workgroup share a SIMD: 168 VGPRs"
+        assert v["lds"] <= 160 * 1024, f"{k}: a workgroup's LDS on gfx950"
+    assert min(v["lds"] for v in scan.values()) <= 80 * 1024, "the one-strip shape fits a CU twice"

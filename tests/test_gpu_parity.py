@@ -282,7 +282,7 @@ def test_chain_threshold_and_tracking_params(lt, oracle):
 def test_scan_and_per_chain_kernel_give_identical_records(lt, oracle, frames_192):
     """The two execution strategies run the same arithmetic on the same strips (grid scan for the idle chains vs
     the per-chain kernel for every chain): their records must agree bit for bit, whatever the scan's
-    segmentation -- including on inputs whose arg-max has exact twins, which the oracle comparison leaves out."""
+    segmentation and the shape of its workgroups -- including on inputs whose arg-max has exact twins, which the oracle comparison leaves out."""
     base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
     iq, _ = siggen.scan_channels(base, 8, 384000, snr_db=15.0, cfo=True, seed0=40)
     n = iq.shape[1]
@@ -291,9 +291,10 @@ def test_scan_and_per_chain_kernel_give_identical_records(lt, oracle, frames_192
                       np.where(t % 4800 == 17, 1.0, 0.0).astype(np.complex64), np.zeros(n, np.complex64)])
     iq = np.concatenate([iq, twins])
     res = []
-    for mode, seg in ((0, None), (1, None), (1, (2, 32)), (1, (1, 5)), (1, (64, 64)), (1, (128, 128))):
+    for mode, seg, groups in ((0, None, 0), (1, None, 0), (1, (2, 32), 1), (1, (1, 5), 2), (1, (64, 64), 3), (1, (128, 128), 3), (1, None, 1), (1, None, 2)):
         b = lt.Batch(iq.shape[0], n)
         b.set_mode(mode)
+        b.set_scan_groups(groups)
         if seg:
             b.set_scan_segments(*seg)
         assert b.mode() == mode
@@ -419,6 +420,12 @@ def test_chain_random_scenes(lt, oracle, frames_192, seed):
     b, got, want = _run_both(lt, oracle, iq, **kw)
     for c in range(3 * n_ch):
         assert_records_match(got[c], want[c], f"seed {seed} {kw} chain {c}")
+    # the benchmark's workgroup shape (three strips; a batch this small runs with one) gives the same bits
+    b3 = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+    b3.set_scan_groups(3)
+    b3.run_host(iq)
+    for c, r in enumerate(b3.collect()):
+        assert r.tobytes() == got[c].tobytes(), f"seed {seed} chain {c}: three strips per workgroup"
 
 
 @pytest.mark.parametrize("seed", [11, 12])

@@ -94,13 +94,16 @@ int main(int argc, char **argv)
   CK(hipMalloc(&dprof, 8 * 128));
   CK(hipMemset(dprof, 0, 8 * 128));
   a.prof = dprof;
-  const int grid = (((n_ch + 7) / 8) * 8 + 8) * kScanWgPerJob;
+  const int G = argc > 5 ? atoi(argv[5]) : 3; // strips per workgroup
+  const int grid = ((n_ch * scan_wg_per_job(G) + 7) / 8) * 8;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (int it = 0; it < 4; ++it) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(lt_scan_kernel, dim3(grid), dim3(kScanThreads), 0, 0, a);
+    if (G == 1) hipLaunchKernelGGL(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, 0, a);
+    else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, 0, a);
+    else hipLaunchKernelGGL(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, 0, a);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
