@@ -38,7 +38,7 @@ STAGES = ("grid_scan", None, "lt_chain_kernel", "per_record")  # lt_batch_phase_
 # kernels rocprofv3 sees per stage (profiles/traffic.json is keyed by kernel name)
 STAGE_KERNELS = {"grid_scan": ("lt_plan_kernel", "lt_scan_kernel", "lt_resolve_kernel"),
                  "lt_chain_kernel": ("lt_chain_kernel",),
-                 "per_record": ("lt_list_kernel", "lt_cfo_kernel", "lt_cfo_ring_kernel", "lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")}
+                 "per_record": ("lt_cfo_kernel", "lt_cfo_ring_kernel", "lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")}
 INT_FIELDS = ("in_pos", "out_pos", "flags", "peak_pos", "score", "m0", "m1", "n_id_1", "cell_id", "timer")
 EXACT_FLOAT_FIELDS = ("cfo", "mean_cfo", "m_norm_avg", "m_ext_avg", "m0_value", "m1_value")
 METRIC_FIELDS = ("psr", "peak_value", "psr_max")

@@ -658,7 +658,6 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
     b->t0 = 0;
     b->hist_len = 0;
   }
-  HIP_TRY(lt::launch_begin(b->d_state, (int)nchains, restart ? 1 : 0, b->d_njobs, set, s));
   const lt_cf32 *d_iq = iq;
   if (!iq_on_device) {
     const size_t bytes = sizeof(lt_cf32) * (size_t)b->n_channels * (size_t)n_samples;
@@ -685,6 +684,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.rec_cap = b->rec_cap;
   R.rec_count = set ? b->d_count_b : b->d_count;
   R.list_slot = set;
+  R.rebase = restart ? 1 : 0;
   R.out_hf = b->d_hf;
   R.out_cap = (int)b->hf_cap;
   R.tab = b->tab;

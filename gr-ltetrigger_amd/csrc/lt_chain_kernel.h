@@ -42,6 +42,8 @@ struct ChainArgs {
   float psr_threshold;
   int track_after;
   int track_every;
+  int2 *list;          // work list of the per-record kernels: (chain, record) of every tracked half-frame of the run
+  int *list_count;
 };
 
 struct SearchResult {
@@ -150,7 +152,7 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[
   return out;
 }
 
-__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
+__device__ __forceinline__ void chain_run(const ChainArgs &a)
 {
   __shared__ ChainLds L;
   __shared__ float psr_data[kMovingAvgSz];
@@ -350,6 +352,28 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
       st->pre_n = 0;
     }
     a.rec_count[chain] = nrec;
+  }
+}
+
+// One workgroup per chain: general_work call by call for whatever the scan rounds have left of it (chain_run), then
+// -- every record of the chain is final now -- the chain's tracked half-frames go onto the work list of the
+// per-record kernels (one atomic per 64 records).
+__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
+{
+  chain_run(a);
+  __threadfence_block();
+  __syncthreads();
+  const int chain = blockIdx.x, lane = threadIdx.x & 63;
+  const int count = a.rec_count[chain];
+  const lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  for (int i = threadIdx.x; i < ((count + 63) & ~63); i += kChainThreads) {
+    const bool ran = i < count && (recs[i].flags & LT_F_SSS_RAN);
+    const unsigned long long m = __ballot(ran);
+    if (!m) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.list_count, __builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (ran) a.list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(chain, i);
   }
 }
 

@@ -1,13 +1,13 @@
 // gfx950 kernels of the LTE cell-search hot path.
 //
 // lt_batch_run / lt_batch_push:
-//   lt_begin_kernel / lt_reset_kernel -- run start (counters, positions) and lt_batch_reset.
+//   lt_reset_kernel    -- lt_batch_reset.
 //   lt_plan_kernel, lt_scan_kernel, lt_resolve_kernel (lt_scan_kernels.h) -- the searches of all chains in rounds,
 //                         strip-wise, exponential averages in registers, one forward transform per block shared by the
 //                         chains of a window sequence; pss_impl::general_work (lib/pss_impl.cc:155-223) on the results.
 //   lt_chain_kernel (lt_chain_kernel.h) -- one workgroup per chain: general_work call by call for whatever the rounds
 //                         leave over (and for every chain in mode 0); one lt_record per call.
-//   lt_list_kernel     -- work list of the tracked half-frames for the per-record kernels:
+//   (the per-record kernels walk a work list of the tracked half-frames that lt_chain_kernel leaves behind:)
 //   lt_cfo_kernel, lt_cfo_ring_kernel -- CFO estimate and mean_cfo() of the tracked half-frames (lib/pss_impl.cc:199-204),
 //   lt_cp_kernel, lt_cp_scan_kernel, lt_sss_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) on them, lt_hf_kernel -- the
 //                         pss block's output stream (optional capture): all per record, afterwards (they feed records only).
@@ -207,26 +207,7 @@ struct CpArgs {
   int *list_count;
 };
 
-// The work list of the per-record kernels: which records carry LT_F_SSS_RAN (the tracked half-frames).  One wave per
-// 64 records of a chain, one atomic per wave.  With the list the per-record kernels start a fixed number of
-// workgroups that walk it, instead of one workgroup per four record slots of every chain, most of them empty.
-constexpr int kListBlocks = 2048; // x 4 waves: eight workgroups per CU
-__global__ __launch_bounds__(256) void lt_list_kernel(CpArgs a)
-{
-  const int chain = blockIdx.x;
-  const int count = a.rec_count[chain];
-  const lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
-  const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < ((count + 63) & ~63); i += 256) {
-    const bool ran = i < count && (recs[i].flags & LT_F_SSS_RAN);
-    const unsigned long long m = __ballot(ran);
-    if (!m) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(a.list_count, __builtin_popcountll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (ran) a.list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(chain, i);
-  }
-}
+constexpr int kListBlocks = 2048; // workgroups (x 4 waves) that walk the work list of the tracked half-frames (built by lt_chain_kernel)
 
 // ---------------------------------------------------------------- CFO of the tracked half-frames
 // srslte_pss_cfo_compute on the uncorrected PSS symbol of every tracked half-frame (lib/pss_impl.cc:199-201):
@@ -670,7 +651,6 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     int rounds = 1;
     if (p.enable) rounds = 1 + (int)((windows - seg_first + seg_len - 1) / seg_len) + R.extra_rounds;
     if (rounds > kMaxRounds) rounds = kMaxRounds;
-    // (the counters behind R.n_jobs are zero: launch_begin)
     // Strips per workgroup: what fills the chip's CUs in the fewest turns at the cost per window measured for each
     // shape (tools/scan_bench.hip: 3.0 / 3.5 / 4.7 us per window of a three-root sequence with 1 / 2 / 3 strips per
     // workgroup); RunLaunch::scan_groups overrides.
@@ -699,7 +679,10 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     p.jobs = jobs2[0];
     p.n_jobs = R.n_jobs;
     p.jobs_cap = s.jobs_cap = n_chains;
-    hipLaunchKernelGGL(lt_plan_kernel, dim3((R.n_channels + 63) / 64), dim3(64), 0, stream, p);
+    p.n_counters = scan_counter_ints();
+    p.keep_counter = 2 * (kMaxRounds + 1) + (R.list_slot ? 0 : 1); // the other run's work-list counter
+    p.rebase = R.rebase;
+    hipLaunchKernelGGL(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
       s.jobs = q.jobs = jobs2[r & 1];
       s.n_jobs = R.n_jobs + 2 * r;
@@ -770,6 +753,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.tab = R.tab; c.psr_threshold = R.psr_threshold; c.track_after = R.track_after;
     c.track_every = R.track_every;
+    // (the work list sits behind the CP metrics in the per-record scratch buffer; its counter behind the job counters)
+    c.list = reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * (size_t)n_chains * (size_t)R.rec_cap);
+    c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
   }
   if (R.ev_chain_done) (void)hipEventRecord(R.ev_chain_done, stream);
@@ -795,7 +781,6 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;
     q.list = c.list; q.list_count = c.list_count;
     const dim3 per_record((unsigned)kListBlocks);
-    hipLaunchKernelGGL(lt_list_kernel, dim3((unsigned)n_chains), dim3(256), 0, rs, c);
     hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, rs, c);
     hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
     hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, rs, c);
@@ -840,24 +825,6 @@ __global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int pa
 hipError_t launch_reset(void *state, int n_chains, int parts, hipStream_t stream)
 {
   hipLaunchKernelGGL(lt_reset_kernel, dim3((unsigned)n_chains), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), parts);
-  return hipGetLastError();
-}
-
-// First launch of a run: the counters of its scan rounds and of its work list start at zero, and a run that is a
-// capture of its own (lt_batch_run) starts its positions at 0 again.
-__global__ void lt_begin_kernel(ChainState *state, int n_chains, int rebase, int *counters, int n_counters, int keep)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (rebase && i < n_chains) state[i].pos = 0;
-  if (i < n_counters && i != keep) counters[i] = 0;
-}
-hipError_t launch_begin(void *state, int n_chains, int rebase, int *counters, int list_slot, hipStream_t stream)
-{
-  const int n_counters = scan_counter_ints();
-  const int n = n_chains > n_counters ? n_chains : n_counters;
-  const int keep = 2 * (kMaxRounds + 1) + (list_slot ? 0 : 1); // the other slot's work-list counter
-  hipLaunchKernelGGL(lt_begin_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), n_chains, rebase,
-                     counters, n_counters, keep);
   return hipGetLastError();
 }
 

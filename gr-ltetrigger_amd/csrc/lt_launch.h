@@ -46,19 +46,16 @@ struct RunLaunch {
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the work list
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr; // (required when the per-record kernels go to a stream of their own)
+  int rebase = 0;             // the run is a capture of its own: the chains' positions restart at 0
   int list_slot = 0;          // which of the two work-list counters behind the job counters this run uses (0 / 1)
 };
 
 // records_stream: null = everything on `stream`; else the per-record kernels (and the half-frame capture) are enqueued
 // there, behind R.ev_chain_done -- the caller orders that stream against whatever reads the records
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t records_stream = nullptr);
-// every chain back to stream position 0 (lt_batch_run: the chunk is a capture of its own)
-// to be launched before launch_run, on the same stream: zeroes the run's counters (RunLaunch::n_jobs) and, for a run that
-// restarts at position 0, the chains' positions
-// chain state back to all zeros; parts: 1 = all but the members only the per-record kernels touch, 2 = those, 3 = both
+// lt_batch_reset: chain state back to the constructor's; parts: 1 = all but the members only the per-record kernels
+// touch, 2 = those, 3 = both
 hipError_t launch_reset(void *state, int n_chains, int parts, hipStream_t stream);
-// (list_slot: the work-list counter of the other slot may still be in use by the run before: it is left alone)
-hipError_t launch_begin(void *state, int n_chains, int rebase, int *counters, int list_slot, hipStream_t stream);
 int call_reach();
 int scan_job_bytes();
 int scan_parts_bytes_per_chain();

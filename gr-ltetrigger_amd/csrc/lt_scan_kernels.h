@@ -343,7 +343,7 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
 struct PlanArgs {
   ChainState *state;
   ScanJob *jobs;     // [jobs_cap]
-  int *n_jobs;       // [2]: jobs allocated from the front (long) / from the back (short); zeroed before the launch
+  int *n_jobs;       // [2]: jobs allocated from the front (long) / from the back (short); zero when the round is planned
   int jobs_cap;
   int *rec_count;    // [n_channels*3]: zeroed in the first round
   int n_channels;
@@ -356,6 +356,8 @@ struct PlanArgs {
   int track_after;
   int track_every;
   int call_reach;    // kCallReach (lt_chain_kernel.h)
+  // first launch of a run only (first_round): counters to clear behind n_jobs, the one to leave alone, positions to 0
+  int n_counters, keep_counter, rebase;
 };
 
 // the job of channel c for the next round
@@ -490,10 +492,20 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
   job->pad = 0;
 }
 
-__global__ void lt_plan_kernel(PlanArgs a)
+// The run's first launch: one workgroup.  It first brings the run's counters to zero (the job counters of every round
+// and this run's work-list counter; `keep` is the other run's, which its per-record kernels may still be using) and,
+// for a run that is a capture of its own, the chains' positions; then it plans the first round.
+__global__ __launch_bounds__(256) void lt_plan_kernel(PlanArgs a)
 {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < a.n_channels) plan_channel(a, c);
+  if (a.first_round) {
+    for (int i = threadIdx.x; i < a.n_counters; i += 256)
+      if (i != a.keep_counter) a.n_jobs[i] = 0;
+    if (a.rebase)
+      for (int i = threadIdx.x; i < a.n_channels * 3; i += 256) a.state[i].pos = 0;
+    __threadfence();
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < a.n_channels; c += 256) plan_channel(a, c);
 }
 
 // ---------------------------------------------------------------- resolve: general_work on the scanned windows

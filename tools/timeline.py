@@ -8,7 +8,7 @@ import os
 f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)  # (the newest, if old runs were merged into the directory)
 rows = [r for r in csv.DictReader(open(f)) if "lt::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "lt_begin_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "lt_plan_kernel" in r["Kernel_Name"]]
 last = rows[idx[-1]:] if idx else rows
 t0 = int(last[0]["Start_Timestamp"])
 for r in last:

@@ -10,7 +10,7 @@ f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = [r for r in csv.DictReader(open(f)) if "lt::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-begins = [i for i, r in enumerate(rows) if "lt_begin_kernel" in r["Kernel_Name"]]
+begins = [i for i, r in enumerate(rows) if "lt_plan_kernel" in r["Kernel_Name"]]
 i0 = begins[-back - 1]
 i1 = begins[-back + 1] if back > 1 else len(rows)
 t0 = int(rows[i0]["Start_Timestamp"])
