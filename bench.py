@@ -229,15 +229,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
-    # kernel time: events on the launch stream around every run inside the timed region
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    # (device time per run and per stage: the library's own HIP events on the launch stream, lt_batch_phase_ms below;
+    # a second pair of events around every run would cost the timed region another ~10 us per step)
     t0 = time.perf_counter()
     for k in range(args.steps):
         batch.reset()
-        ev[k][0].record(tstream)
         batch.run_device(iq_real.data_ptr(), n, stream)
-        ev[k][1].record(tstream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -252,14 +249,14 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if args.overlap:
-        # the events above bracket what a run puts on the launch stream; its per-record kernels are on the batch's second
-        # stream, beside the next step: the path's time per step is the timed region's
-        kernel_ms = elapsed / args.steps * 1e3
     # per stage: the library's own HIP events on the launch stream, of the last (up to 8) timed steps
     phases = np.array([batch.phase_ms(k) for k in range(min(args.steps, 8))], dtype=np.float64)
     phase_ms = phases.mean(axis=0)
+    kernel_ms = float(phase_ms.sum())  # a run, first launch to last
+    if args.overlap:
+        # a run's per-record kernels are on the batch's second stream, beside the next step: the path's time per step
+        # is the timed region's
+        kernel_ms = elapsed / args.steps * 1e3
 
     # correctness of what was timed: cell_id match on this rank's channels
     recs = batch.collect()
