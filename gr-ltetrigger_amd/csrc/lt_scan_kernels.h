@@ -662,6 +662,53 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
         need_chain = true;
         break;
       }
+      // ---- a chain building its score (lib/pss_impl.cc:111-127, 184-214): hits that leave the peak where it is,
+      // short of the one that starts tracking -- one lane each: the score goes up by one per window, every half-frame
+      // is emitted with the tracking_lost tag (quirk q2).
+      if (!is_tracking && !tracking_lost && !ema_reset && !in_c && score + 1 < a.track_after) {
+        const int seg_end = job.n_b - blk < nb ? job.n_b - blk : nb;
+        const int t = lane - k; // this lane's window, counted from k
+        const int64_t my_pos = pos + (int64_t)t * kHalfFrame;
+        const bool mine = lane >= k && lane < seg_end && score + t + 1 < a.track_after;
+        const bool fits = mine && my_pos <= limit && my_pos + kHalfFrame <= a.t1 && nrec + t + 1 <= a.rec_cap;
+        const bool hit = fits && wr.exact && wr.psr > a.psr_threshold && wr.peak_pos == kSlotLen;
+        const unsigned long long bad = ~__ballot(hit) & (~0ull << k);
+        const int m = (bad ? __builtin_ctzll(bad) : 64) - k; // windows k .. k + m - 1
+        if (m > 1) {
+          const bool on = lane >= k && lane < k + m;
+          float pm = on ? wr.psr : -FLT_MAX; // d_psr_max as an inclusive prefix maximum
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(pm, d);
+            if (lane >= d) pm = fmaxf(pm, o);
+          }
+          const float my_max = fmaxf(psr_max, pm);
+          if (on) {
+            lt_record r;
+            r.in_pos = my_pos; r.out_pos = my_pos; r.channel = channel; r.n_id_2 = n_id_2;
+            r.call_idx = call_base + nrec + t;
+            r.flags = LT_F_SEARCHED | LT_F_OVER | LT_F_EMITTED | LT_F_TAG_LOST;
+            r.peak_pos = kSlotLen; r.score = score + t + 1; r.psr = wr.psr; r.peak_value = wr.peak_value;
+            r.cfo = 0.f; r.mean_cfo = 0.f; r.m_norm_avg = 0.f; r.m_ext_avg = 0.f; r.m0_value = 0.f; r.m1_value = 0.f;
+            r.m0 = -1; r.m1 = -1; r.n_id_1 = -1; r.cell_id = -1; r.psr_max = my_max; r.timer = a.track_every;
+            recs[nrec + t] = r;
+            st->psr_data[(psr_i + (uint32_t)t) % kMovingAvgSz] = wr.psr;
+          }
+          psr_max = rlane(my_max, k + m - 1);
+          psr = rlane(wr.psr, k + m - 1);
+          peak_pos = kSlotLen;
+          timer = a.track_every;
+          score += m;
+          psr_i += (uint32_t)m;
+          nrec += m;
+          n_emits += m;
+          pos += (int64_t)m * kHalfFrame;
+          used = blk + k + m;
+          k += m - 1;
+          off = false;
+          continue;
+        }
+      }
       // ---- a tracked chain in its steady state (score at track_after, every search a hit that leaves the peak where
       // it is): the searches up to the first window that is anything else, one lane each -- the search's record and
       // those of the track_every calls behind it (lib/pss_impl.cc:163-204 with frame_start = 0).
