@@ -44,7 +44,7 @@ EXPORTS = [
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
     "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms", "lt_batch_push",
-    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_set_scan_groups",
+    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_debug_hold_records", "lt_batch_set_scan_groups",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
 
@@ -124,6 +124,7 @@ def lib():
     L.lt_batch_get_mode.argtypes = [vp]
     L.lt_batch_set_scan_segments.argtypes = [vp, i32, i32]
     L.lt_batch_set_overlap.argtypes = [vp, i32]
+    L.lt_batch_debug_hold_records.argtypes = [vp, i32]
     L.lt_batch_set_scan_groups.argtypes = [vp, i32]
     L.lt_batch_collect.argtypes = [vp, vp, i64, vp]
     L.lt_batch_record_capacity.argtypes = [i64]
@@ -338,6 +339,10 @@ class Batch:
     def set_overlap(self, on):
         """Per-record kernels of a device run beside the next run's scan rounds (lt_batch_set_overlap)."""
         _check(lib().lt_batch_set_overlap(self._h, 1 if on else 0), "lt_batch_set_overlap")
+
+    def debug_hold_records(self, microseconds):
+        """Diagnostics: every run's per-record kernels start this much later (lt_batch_debug_hold_records)."""
+        _check(lib().lt_batch_debug_hold_records(self._h, int(microseconds)), "lt_batch_debug_hold_records")
 
     def set_scan_segments(self, first, later):
         _check(lib().lt_batch_set_scan_segments(self._h, int(first), int(later)), "lt_batch_set_scan_segments")

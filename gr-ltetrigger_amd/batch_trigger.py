@@ -44,7 +44,12 @@ class BatchTrigger:
         n = iq_tensor.shape[1]
         if stream is None:
             # the stream the tensor's producer ran on: the library's own stream would not be ordered behind it
-            stream = torch.cuda.current_stream(iq_tensor.device).cuda_stream
+            cur = torch.cuda.current_stream(iq_tensor.device)
+            stream = cur.cuda_stream
+            if not stream:
+                # torch's default stream has the handle 0, which the C-ABI reads as "use the batch's own (non-blocking)
+                # stream": nothing would order that one behind the producer, so wait for the producer here
+                cur.synchronize()
         self.batch.reset()
         self.batch.run_device(torch.view_as_real(iq_tensor).data_ptr(), n, stream)
         recs = self.batch.collect()

@@ -178,6 +178,7 @@ struct lt_batch {
   hipEvent_t rec_done[2] = {nullptr, nullptr};
   bool rec_done_valid[2] = {false, false};
   bool side_busy = false;          // something may still be running on `side`
+  int records_delay_us = 0;        // lt_batch_debug_hold_records
   lt_record *cur_recs = nullptr;   // the set the last run wrote
   int *cur_count = nullptr;
 };
@@ -604,6 +605,9 @@ int lt_batch_set_psr_threshold(lt_batch *b, float threshold)
 int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain)
 {
   if (!b || max_per_chain < 0) return fail(LT_ERROR_INVALID_INPUTS, "invalid argument");
+  if (max_per_chain > 0 && b->rec_cap > 65535)
+    return fail(LT_ERROR_INVALID_INPUTS, "half-frame capture needs max_samples below %lld (one grid row per record slot: at most 65535; this batch has %d)",
+                (long long)65535 * (LT_HALF_FRAME_LEN - LT_SLOT_LEN), b->rec_cap);
   HIP_TRY(hipSetDevice(b->device));
   if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
   if (b->side_busy) HIP_TRY(hipStreamSynchronize(b->side));
@@ -700,6 +704,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.scan_groups = b->scan_groups;
   R.n_cus = b->n_cus;
   R.cp_scratch = b->d_cp;
+  R.records_delay_us = b->records_delay_us;
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
   R.ev_scan_done = b->ev[slot][1];
   R.ev_chain_done = b->ev[slot][2];
@@ -863,6 +868,13 @@ int lt_batch_set_overlap(lt_batch *b, int on)
     }
   }
   b->overlap = on;
+  return LT_OK;
+}
+
+int lt_batch_debug_hold_records(lt_batch *b, int microseconds)
+{
+  if (!b || microseconds < 0 || microseconds > 100000) return fail(LT_ERROR_INVALID_INPUTS, "hold must be within [0, 100000] us");
+  b->records_delay_us = microseconds;
   return LT_OK;
 }
 

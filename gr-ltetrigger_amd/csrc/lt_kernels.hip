@@ -588,6 +588,14 @@ __global__ __launch_bounds__(256) void lt_hist_kernel(HistArgs a)
   a.hist_new[(int64_t)c * a.hist_stride + i] = v;
 }
 
+// Diagnostics (lt_batch_debug_hold_records): one wave that sits on its stream for `ticks` of the 100 MHz wall clock,
+// so that a test can hold a run's per-record kernels back until the next run's launches are through.
+__global__ __launch_bounds__(64) void lt_delay_kernel(long long ticks)
+{
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+
 } // namespace lt
 
 // Host-callable launchers (the C-ABI in lt_api.cpp only sees these).
@@ -607,13 +615,26 @@ int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips *
 int scan_max_round() { return kScanMaxRound; }
 int scan_max_rounds() { return kMaxRounds; }
 int scan_counter_ints() { return 2 * (kMaxRounds + 1) + 2; } // job counters of every round + the per-record work list's
-int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + sizeof(int2)); }
+int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + 2 * sizeof(int2)); } // CP metrics + one work-list entry for each of the two list slots
+
+// The work lists sit behind the CP metrics in the per-record scratch buffer, one per list slot (their counters
+// behind the job counters): with lt_batch_set_overlap the per-chain kernel of run k + 1 fills its list on the main
+// stream while the per-record kernels of run k still walk theirs on the side stream.
+static int2 *work_list(const RunLaunch &R, int n_chains)
+{
+  const size_t per_slot = (size_t)n_chains * (size_t)R.rec_cap;
+  return reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * per_slot) + (R.list_slot ? per_slot : 0);
+}
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t records_stream)
 {
   const int n_chains = R.n_channels * 3;
   if (R.rec_cap <= 0 || n_chains <= 0) return hipErrorInvalidValue;
   if ((R.rec_cap + 3) / 4 > 65535) return hipErrorInvalidValue; // (a chunk of > 37 minutes)
+  // (lt_hf_kernel: one grid row per record slot; checked here, before anything is enqueued -- lt_batch_enable_halfframes
+  // refuses the combination with a message of its own)
+  if (R.out_hf && R.out_cap > 0 && R.rec_cap > 65535) return hipErrorInvalidValue;
+  static const bool debug_jobs = getenv("LT_DEBUG_JOBS") != nullptr; // (read once: this is the launch path of every run)
   const v2f *iq = reinterpret_cast<const v2f *>(R.iq);
   const v2f *hist = reinterpret_cast<const v2f *>(R.hist);
   ChainState *state = reinterpret_cast<ChainState *>(R.state);
@@ -696,7 +717,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
       else hipLaunchKernelGGL(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
       hipLaunchKernelGGL(lt_resolve_kernel, dim3(R.n_channels), dim3(192), 0, stream, q);
-      if (getenv("LT_DEBUG_JOBS")) { // diagnostics: the jobs of this round
+      if (debug_jobs) { // diagnostics: the jobs of this round
         (void)hipStreamSynchronize(stream);
         int njj[2] = {0, 0};
         (void)hipMemcpy(njj, R.n_jobs + 2 * r, sizeof(njj), hipMemcpyDeviceToHost);
@@ -726,7 +747,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       }
     }
   }
-  if (getenv("LT_DEBUG_JOBS")) { // diagnostics: what the rounds leave to the per-chain kernel
+  if (debug_jobs) { // diagnostics: what the rounds leave to the per-chain kernel
     (void)hipStreamSynchronize(stream);
     std::vector<char> hs((size_t)n_chains * sizeof(ChainState));
     (void)hipMemcpy(hs.data(), state, hs.size(), hipMemcpyDeviceToHost);
@@ -753,8 +774,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.tab = R.tab; c.psr_threshold = R.psr_threshold; c.track_after = R.track_after;
     c.track_every = R.track_every;
-    // (the work list sits behind the CP metrics in the per-record scratch buffer; its counter behind the job counters)
-    c.list = reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * (size_t)n_chains * (size_t)R.rec_cap);
+    c.list = work_list(R, n_chains);
     c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
   }
@@ -773,21 +793,20 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.iq = iq; c.ch_stride = R.ch_stride; c.hist = hist; c.hist_stride = R.hist_stride; c.t0 = R.t0; c.n = R.n;
     c.hist_len = R.hist_len; c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.metrics = reinterpret_cast<CpMetrics *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
-    // (the work list sits behind the metrics in the same scratch buffer; its counter behind the job counters)
-    c.list = reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * (size_t)n_chains * (size_t)R.rec_cap);
+    c.list = work_list(R, n_chains);
     c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
     SssArgs q;
     q.iq = iq; q.ch_stride = R.ch_stride; q.hist = hist; q.hist_stride = R.hist_stride; q.t0 = R.t0; q.n = R.n;
     q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;
     q.list = c.list; q.list_count = c.list_count;
     const dim3 per_record((unsigned)kListBlocks);
+    if (R.records_delay_us > 0) hipLaunchKernelGGL(lt_delay_kernel, dim3(1), dim3(64), 0, rs, (long long)R.records_delay_us * 100);
     hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, rs, c);
     hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
     hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, rs, c);
     hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
     hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, rs, q);
     if (R.out_hf && R.out_cap > 0) {
-      if (R.rec_cap > 65535) return hipErrorInvalidValue;
       HfArgs h;
       h.iq = iq; h.ch_stride = R.ch_stride; h.hist = hist; h.hist_stride = R.hist_stride; h.t0 = R.t0; h.n = R.n;
       h.hist_len = R.hist_len; h.recs = R.recs; h.rec_cap = R.rec_cap; h.rec_count = R.rec_count;

@@ -43,11 +43,12 @@ struct RunLaunch {
   int scan_groups = 0;        // strips per scan workgroup: 1, 2 or 3; 0 = chosen from n_channels and n_cus
   int n_cus = 0;              // compute units of the device (0: 256)
   int extra_rounds = 2;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
-  void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the work list
+  void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the two work lists
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr; // (required when the per-record kernels go to a stream of their own)
   int rebase = 0;             // the run is a capture of its own: the chains' positions restart at 0
-  int list_slot = 0;          // which of the two work-list counters behind the job counters this run uses (0 / 1)
+  int records_delay_us = 0;   // diagnostics (lt_batch_debug_hold_records): the per-record kernels start this much later
+  int list_slot = 0;          // which of the two work lists (and of their counters behind the job counters) this run uses (0 / 1)
 };
 
 // records_stream: null = everything on `stream`; else the per-record kernels (and the half-frame capture) are enqueued

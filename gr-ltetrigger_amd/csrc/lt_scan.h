@@ -83,56 +83,91 @@ __device__ __forceinline__ float wave_max_dpp(float f)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
 }
 
-// e[r] = average of lag c0 + lane + 64 r (r < 14; e[14], e[15] = -FLT_MAX).  Wave-uniform result in `out` (every
-// lane holds it).  Works on the registers in place -- four of them are patched and put back -- because a masked
-// copy of the tuple would cost 16 moves per window.
-__device__ __forceinline__ void strip_resolve(ema_t &e, int s, int lane, StripPartial &out)
+// minimum of a non-negative key over the wave (same shape as wave_max_dpp)
+__device__ __forceinline__ int wave_min_key_dpp(int k)
+{
+  asm("s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(k));
+  return __builtin_amdgcn_readlane(k, 63);
+}
+
+// e[r] = average of lag c0 + lane + 64 r (r < 14; e[14], e[15] are spare: the tuple has a power-of-two size).  Wave-uniform result in `out` (every
+// lane holds it).  The tuple is only read -- two of its registers through a run-time, wave-uniform index (the rows the
+// peak and its neighbourhood sit in) -- so the average stays where the update left it.
+//
+// One pass over the 14 registers gives every lane its maximum m, where it sits (a: the first register) and its second
+// largest value m2 (v_med3: the median of the old maximum, the new value and the old second is the new second).  The
+// strip's maximum is the wave maximum of m.  The maximum outside the main lobe needs no second pass: the 64 lags
+// around the peak are one value per lane (`row`); outside that window a lane contributes m -- or m2 where its
+// maximum IS its window value --, inside it the window value unless the lobe covers it.
+__device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, StripPartial &out)
 {
   const int c0 = kStripPitch * s - kStripHalo;
   // owned and valid lags: offsets [41, 852) of the computed range, lag < 9726 (strip 11 ends at offset 845):
   // the halo lags in registers 0 and 13 sit out the two maxima
-  const bool own0 = lane >= kStripHalo;
   const int own13_end = (s == kStrips - 1) ? (kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13)
                                            : (kStripHalo + kStripPitch - 64 * 13);
-  const bool own13 = lane < own13_end;
-  const float full0 = e[0], full13 = e[13];
-  e[0] = own0 ? full0 : -FLT_MAX;
-  e[13] = own13 ? full13 : -FLT_MAX;
-  // 1. maximum over the owned lags, by groups of three registers, and where it sits (first in lag order:
-  // smallest register, then lane): first group that holds it, first register of that group
-  float g[5];
+  const uint64_t halo0 = (1ull << kStripHalo) - 1ull, halo13 = ~((1ull << own13_end) - 1ull); // lanes of register 0 / 13 that sit out
+  const bool own0 = lane >= kStripHalo, own13 = lane < own13_end;
+  // 1. per lane: maximum, its register (the first), second largest
+  float m = own0 ? e[0] : -FLT_MAX, m2 = -FLT_MAX;
+  int a = 0;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) g[i] = fmaxf(fmaxf(e[3 * i], e[3 * i + 1]), e[3 * i + 2]); // (e[14] = -FLT_MAX)
-  const float M1 = wave_max_dpp(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
-  int gi = 0;
-#pragma unroll
-  for (int i = 4; i >= 0; --i)
-    if (__ballot(g[i] == M1)) gi = i;
-  gi = __builtin_amdgcn_readfirstlane(gi);
-  const float c0v = e[3 * gi], c1v = e[3 * gi + 1], c2v = e[3 * gi + 2]; // (run-time register index, wave-uniform)
-  const uint64_t b0 = __ballot(c0v == M1), b1 = __ballot(c1v == M1), b2 = __ballot(c2v == M1);
-  uint64_t bal = b0 ? b0 : b1 ? b1 : b2;
-  int r_p = 3 * gi + (b0 ? 0 : b1 ? 1 : 2);
+  for (int r = 1; r < kStripRegs; ++r) {
+    const float v = (r == kStripRegs - 1) ? (own13 ? e[r] : -FLT_MAX) : e[r];
+    // a = v > m ? r : a (strictly greater: the first register keeps a tie); m2 = med3(m, v, m2); m = max(m, v).
+    // (As assembly: written with fmaxf / fmed3f every value first goes through a canonicalising v_max x, x.)
+    asm("v_cmp_gt_f32 vcc, %[v], %[m]\n\t"
+        "v_cndmask_b32_e64 %[a], %[a], %[r], vcc\n\t"
+        "v_med3_f32 %[m2], %[m], %[v], %[m2]\n\t"
+        "v_max_f32 %[m], %[m], %[v]"
+        : [a] "+v"(a), [m2] "+v"(m2), [m] "+v"(m)
+        : [v] "v"(v), [r] "n"(r)
+        : "vcc");
+  }
+  const float M1 = wave_max_dpp(m);
+  // where it sits, first in lag order: smallest register, then lane
+  const uint64_t hit = __ballot(m == M1);
   uint32_t flags = 0;
-  if (!bal || r_p >= kStripRegs) { // only a NaN can do that: outside the contract, but stay in bounds
-    bal = 1ull << kStripHalo;
+  int l_p, r_p;
+  if (__builtin_popcountll(hit) == 1) {
+    l_p = __builtin_ctzll(hit);
+    r_p = __builtin_amdgcn_readlane(a, l_p);
+  } else if (hit) { // (an exact tie between lanes: degenerate inputs)
+    const int key = wave_min_key_dpp(m == M1 ? a * 64 + lane : 0x7FFFFFFF);
+    l_p = key & 63;
+    r_p = key >> 6;
+  } else { // only a NaN can do that: outside the contract, but stay in bounds
+    l_p = kStripHalo;
     r_p = 0;
     flags = kPartWide;
   }
-  r_p = __builtin_amdgcn_readfirstlane(r_p);
-  const int l_p = __builtin_ctzll(bal);
   const int p1 = c0 + l_p + 64 * r_p;
   // 2. the lags p1 - 32 .. p1 + 31 as one rotated row: lane L holds offset (L - l_p) wrapped to [-32, 32).
   // Offsets that fall off this register's 64 lanes come from the register before (l_p < 32) or after it
   // (which exists whenever a lane needs it: the peak is an owned lag).
   const int r_b = (l_p < 32) ? (r_p > 0 ? r_p - 1 : 1) : (r_p < kStripRegs - 1 ? r_p + 1 : kStripRegs - 2);
-  const float mA = e[r_p], mB = e[r_b]; // as patched: what the second maximum has to put back
-  const float rowA = (r_p == 0) ? full0 : (r_p == kStripRegs - 1) ? full13 : mA;
-  const float rowB = (r_b == 0) ? full0 : (r_b == kStripRegs - 1) ? full13 : mB;
-  const bool use_b = (l_p < 32) ? (lane >= l_p + 32) : (lane < l_p - 32);
+  const float rowA = e[r_p], rowB = e[r_b]; // (run-time register index, wave-uniform)
+  const int d = lane - l_p;
+  const int off = ((d + 32) & 63) - 32;
+  const bool use_b = d != off; // the offset wrapped: the lag sits in the neighbouring register
   const float row = use_b ? rowB : rowA;
+  // the same with the halo lanes out (the window's share of the second maximum): which lanes of the row sit out is a
+  // wave-uniform mask, handed to v_cndmask as the scalar pair it is (written as a test of bit `lane` it becomes a 64-bit
+  // vector shift)
+  const uint64_t outA = r_p == 0 ? halo0 : r_p == kStripRegs - 1 ? halo13 : 0ull;
+  const uint64_t outB = r_b == 0 ? halo0 : r_b == kStripRegs - 1 ? halo13 : 0ull;
+  const uint64_t wrapped = __ballot(use_b);
+  const uint64_t sits_out = (wrapped & outB) | (~wrapped & outA);
+  float row_own;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(row_own) : "v"(row), "v"(-FLT_MAX), "s"(sits_out));
   const float nxt = wave_next(row), prv = wave_prev(row);
-  const int off = ((lane - l_p + 32) & 63) - 32;
   const int lag_row = p1 + off;
   // main-lobe walk (oracle/lte_oracle.c:300-308): right while avg[u+1] <= avg[u] and u < 9727, left while
   // avg[l-1] <= avg[l] and l > 1; no left walk for a peak at lag <= 2
@@ -147,26 +182,19 @@ __device__ __forceinline__ void strip_resolve(ema_t &e, int s, int lane, StripPa
   else if (ml) j_l = 1 + __builtin_clzll(ml);
   else flags |= kPartWide;
   const int lb = p1 - j_l, ub = p1 + j_r;
-  // 3. maximum over the owned lags outside [lb, ub).  The lobe's lags sit in registers r_p / r_b of the lanes
-  // at offsets [-j_l, j_r): knock those out, take the maximum again, put them back.
-  const uint64_t lobe_rot = ((1ull << j_r) - 1ull) | (j_l ? (~0ull << (64 - j_l)) : 0ull);
-  const uint64_t lobe = rotl64(lobe_rot, l_p);
-  const bool in_lobe = (lobe >> lane) & 1ull;
-  e[r_p] = (in_lobe && !use_b) ? -FLT_MAX : mA;
-  e[r_b] = (in_lobe && use_b) ? -FLT_MAX : mB;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) g[i] = fmaxf(fmaxf(e[3 * i], e[3 * i + 1]), e[3 * i + 2]);
-  const float S = wave_max_dpp(fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), fmaxf(g[3], g[4])));
-  e[r_p] = mA;
-  e[r_b] = mB;
-  e[0] = full0;
-  e[13] = full13;
+  // 3. maximum over the owned lags outside [lb, ub): the lobe is the window's offsets [-j_l, j_r)
+  const bool in_lobe = (unsigned)(off + j_l) < (unsigned)(j_l + j_r);
+  const float far = (row_own == m) ? m2 : m; // (a tie: m2 == m, either is right)
+  const float near = in_lobe ? -FLT_MAX : row_own;
+  float both; // (as assembly: fmaxf would canonicalise both operands first)
+  asm("v_max_f32 %0, %1, %2" : "=v"(both) : "v"(far), "v"(near));
+  const float S = wave_max_dpp(both);
   out.m1 = M1;
   out.p1 = p1;
   out.s = S;
   out.lb = lb;
   out.ub = ub;
-  out.a0 = (s == 0) ? rlane(full0, kStripHalo) : 0.f;
+  out.a0 = (s == 0) ? rlane(e[0], kStripHalo) : 0.f;
   out.flags = flags;
   out.pad = 0;
 }
@@ -253,7 +281,12 @@ __device__ __forceinline__ void strip_load(const Capture &c, int64_t w0, int s, 
     // The window as a buffer resource of 9600 samples: the block's samples in front of the window (negative
     // offsets, huge as unsigned) and behind it are out of range, and an out-of-range buffer load returns zero --
     // the window's zero pads without a compare, and one 32-bit offset per load instead of a 64-bit address.
-    const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(c.iq + (w0 - c.t0)), 0, kHalfFrame * (int)sizeof(v2f), 0x00020000);
+    // (the window's address is wave-uniform, but the compiler cannot always prove it -- a loop counter it keeps in a
+    // vector register is enough -- and a resource it takes for divergent is built lane by lane in a waterfall loop
+    // around EVERY load: 14 instructions instead of one.  v_readfirstlane states the fact.)
+    const uint64_t wa = (uint64_t)(c.iq + (w0 - c.t0));
+    const uint32_t wa_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wa), wa_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wa >> 32));
+    const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)wa_hi << 32) | wa_lo), 0, kHalfFrame * (int)sizeof(v2f), 0x00020000);
     const int off = i0 * (int)sizeof(v2f);
 #pragma unroll
     for (int R = 0; R < 16; ++R) {
@@ -304,22 +337,26 @@ __device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32
   const bool valid0 = !(s == 0 && lane < kStripHalo);
   const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13; // strip 11: lanes below hold lags < 9726
   const bool valid13 = !(s == kStrips - 1 && lane >= end13);
-  // (written on whole vectors so that the products and sums pair up in place, in the tuple's own registers)
-  ema_t met;
+  // (pair by pair, in the tuple's own registers: two packed products and a packed sum per two lags)
+  typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const fft::c32 y = v[r < kStripRegs ? r + 2 : 0];
-    const fft::c32 sq = y * y;
-    float m; // (as assembly: left to itself the compiler shuffles two lags' squares into pairs to add them packed)
-    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(sq.x), "v"(sq.y));
-    met[r] = m;
+  for (int r = 0; r < kStripRegs; r += 2) {
+    f2 met;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const fft::c32 y = v[r + h + 2];
+      const fft::c32 sq = y * y;
+      float m; // (as assembly: left to itself the compiler shuffles two lags' squares into pairs to add them packed)
+      asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(sq.x), "v"(sq.y));
+      met[h] = m;
+    }
+    const f2 old = {ema[r], ema[r + 1]};
+    const f2 ne = met * 0.2f + old * (1.0f - 0.2f); // (no contraction: the build has -ffp-contract=off)
+    ema[r] = ne.x;
+    ema[r + 1] = ne.y;
   }
-  ema_t ne = met * 0.2f + ema * (1.0f - 0.2f); // (no contraction: the build has -ffp-contract=off)
-  ne[0] = valid0 ? ne[0] : 0.f;
-  ne[kStripRegs - 1] = valid13 ? ne[kStripRegs - 1] : 0.f;
-  ne[14] = -FLT_MAX;
-  ne[15] = -FLT_MAX;
-  ema = ne;
+  ema[0] = valid0 ? ema[0] : 0.f;
+  ema[kStripRegs - 1] = valid13 ? ema[kStripRegs - 1] : 0.f;
 }
 
 // One window of one root of one strip: spectrum of the block (X) times the filter spectrum, back to the lag

@@ -304,6 +304,7 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       if (lane == 0) __hip_atomic_store(&sync_taken[g][root], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       LT_PSTAMP(1) // last forward stage
       if (k == sq.n_a + sq.n_b && sq.n_c > 0) { // tracking starts here: srslte_pss_reset
+        asm volatile("; the average cleared" ::: "memory"); // (a branch taken once a round, not fourteen selects per window)
 #pragma unroll
         for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
       }

@@ -180,6 +180,10 @@ int lt_batch_get_mode(lt_batch *b);
  * buffer of a run must stay untouched until then.  lt_batch_push and runs from host memory are not overlapped.
  * Same records either way. */
 int lt_batch_set_overlap(lt_batch *b, int on);
+/* Diagnostics: hold every run's per-record kernels back by `microseconds` (0 = off, at most 100000) on the stream they
+ * are enqueued on.  With overlap on, this opens the window in which a run's per-record kernels and the next run's
+ * launches are in flight together as wide as a test wants it.  Records are the same with any hold. */
+int lt_batch_debug_hold_records(lt_batch *b, int microseconds);
 /* The grid scan runs in rounds of windows; a chain that fires leaves the scan at the end of its round.
  * first = windows in the first round (default 2: cells present from the start of a capture fire at once),
  * later = windows in every following round, at most 128 (default 0: the chunk's windows split evenly over as few
@@ -217,8 +221,9 @@ int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_
  * may also finish calls left over from the one before). */
 int64_t lt_batch_record_capacity(int64_t n_samples);
 /* Optional capture of the emitted (CFO-corrected) half-frames = the pss block's output stream
- * (lib/pss_impl.cc:188-193,204).  max_per_chain = 0 disables.  Read back with
- * lt_batch_get_halfframes: out = [max_per_chain][9600] for one chain. */
+ * (lib/pss_impl.cc:188-193,204).  max_per_chain = 0 disables.  Refused (LT_ERROR_INVALID_INPUTS) for a batch
+ * whose max_samples gives more than 65535 record slots per chain (about 9.4 minutes at 1.92 Msps).  Read back
+ * with lt_batch_get_halfframes: out = [max_per_chain][9600] for one chain. */
 int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain);
 int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, int64_t *count);
 /* Device time of the chain kernel of the last run, in milliseconds (HIP events on the run's stream). */

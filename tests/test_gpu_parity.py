@@ -486,6 +486,41 @@ def test_overlap_gives_the_same_records(lt, oracle, frames_192):
 
 
 @pytest.mark.parametrize("mode", [1, 0])
+def test_overlap_with_the_next_run_in_flight(lt, oracle, frames_192, mode):
+    """The window the overlap mode opens, held open: every run's per-record kernels are kept back (3 ms, far longer than
+    a run of these short captures) so that the next run's launches -- its per-chain kernel fills the next work list --
+    are through before they start.  Runs back to back on alternating captures, nothing collected in between, no reset:
+    the last run's records (their CFO ring mean and CP averages carry every earlier run's) are those of the same
+    sequence without overlap, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
+    a, _ = siggen.scan_channels(base, 5, 40 * 9600 + 77, snr_db=15.0, cfo=True, seed0=170)
+    b2, _ = siggen.scan_channels(base[::-1], 5, 40 * 9600 + 77, snr_db=9.0, cfo=True, seed0=180)
+    bufs = [torch.from_numpy(a).to(dev), torch.from_numpy(b2).to(dev)]
+    n = a.shape[1]
+    s = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    seq = [0, 1, 1, 0, 1, 0]
+
+    def run(overlap, hold_us):
+        bt = lt.Batch(5, n)
+        bt.set_mode(mode)
+        bt.set_overlap(overlap)
+        bt.debug_hold_records(hold_us)
+        for k in seq:
+            bt.run_device(torch.view_as_real(bufs[k]).data_ptr(), n, s.cuda_stream)
+        return [r.copy() for r in bt.collect()]
+
+    ref = run(False, 0)
+    assert sum(int(((r["flags"] & lt.F_SSS_RAN) != 0).sum()) for r in ref) > 50, "the scene must put tracked half-frames on the work list"
+    for hold in (3000, 0):
+        got = run(True, hold)
+        for c in range(15):
+            assert got[c].tobytes() == ref[c].tobytes(), f"hold {hold} us, chain {c}"
+
+
+@pytest.mark.parametrize("mode", [1, 0])
 def test_reset_is_a_fresh_batch(lt, oracle, frames_192, mode):
     """lt_batch_reset declares the averages zero instead of clearing them (and clears the rest of the state): a
     batch that has run on one capture, is reset and runs on another gives the records of a fresh batch, bit for bit."""

@@ -1,5 +1,7 @@
+"""Replay a scene saved by tools/stress_parity.py (--out: scene_*.npz) and list the first records that differ."""
 import sys, os, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import ltetrigger_amd as lt
 from oracle import oracle as O
