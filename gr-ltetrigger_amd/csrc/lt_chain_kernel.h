@@ -54,9 +54,9 @@ struct SearchResult {
 
 // LDS of the chain kernel / the single-call find kernel
 struct ChainLds {
-  v2f E[kChainWaves * fft::kScratchW]; // exchange areas; the exact path's mirror of the average lives here too
-  fft::c32 TW1[16 * 64];
-  fft::c32 TW2[16 * 4];
+  alignas(16) v2f E[kChainWaves * fft::kScratchW]; // exchange areas; the exact path's mirror of the average lives here too
+  alignas(16) fft::c32 TW1[fft::kTw1Len];
+  alignas(16) fft::c32 TW2[fft::kTw2Len];
   v2f SPEC[fft::kN];
   StripPartial parts[2][kStrips];      // two sets used in turn: no barrier between a resolve and the next search
   float wave_out[kChainWaves];
@@ -65,8 +65,8 @@ static_assert(sizeof(v2f) * kChainWaves * fft::kScratchW >= sizeof(float) * (kCo
 
 __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *__restrict__ tab, int n_id_2)
 {
-  for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) L.TW1[i] = *reinterpret_cast<const fft::c32 *>(tab->fft_tw1[i]);
-  if (threadIdx.x < 64) L.TW2[threadIdx.x] = *reinterpret_cast<const fft::c32 *>(tab->fft_tw2[threadIdx.x]);
+  for (int i = threadIdx.x; i < fft::kTw1Len; i += blockDim.x) L.TW1[i] = *reinterpret_cast<const fft::c32 *>(tab->fft_tw1[i]);
+  for (int i = threadIdx.x; i < fft::kTw2Len; i += blockDim.x) L.TW2[i] = *reinterpret_cast<const fft::c32 *>(tab->fft_tw2[i]);
   for (int i = threadIdx.x; i < fft::kN; i += blockDim.x) {
     const cf32 h = tab->pss_spec[n_id_2][i];
     L.SPEC[i] = v2f{h.re, h.im};

@@ -115,54 +115,94 @@ template <int S, bool kInv> LT_HD void fft16(c32 *v)
 //   stage B  radix-16 over s:    b[t] = sum_s E1[k1][c + 4 s] W16^(s t),  times W64^(c t)
 //   exchange 2                   E2[c][k1 + 16 t]  ->  lane l reads E2[0..3][l + 64 i], i = 0..3
 //   stage C  radix-4 over c:     X[(l + 64 i) + 256 u] = sum_c E2[c][l + 64 i] W4^(c u)   (reg i + 4 u)
-// Row strides 68 (E1) and 260 (E2): conflict-free under both banking rules of MI355X_MICROARCH.md (b64 reads:
-// two groups of 32 lanes on 64 banks; b64 writes and the read2 forms: four groups of 16 lanes on 32 banks).
-// (264 for E2 put rows c and c + 2 of a 16-lane write group on the same banks: SQ_LDS_BANK_CONFLICT 13 %.)
+// LDS layouts, chosen by what the reads cost (MI355X_MICROARCH.md, LDS: ds_read_b64 and ds_read_b128 deliver 256 bytes
+// per clock, the two-address forms the compiler merges separate 8-byte reads into only 128):
+//   E1[16][68]: within a row the element l = c + 4 s sits at 8 (s / 2) + 2 c + (s % 2), so that lane (k1, c) reads its
+//     sixteen s as eight 16-byte pairs.  A 16-lane group of the 8-byte stores writes 16 consecutive entries of one row:
+//     conflict-free whatever the row stride.  The 16-byte reads of a group come from four rows (k1 = 0, 3, 5, 6 and the
+//     like), 16 banks each; at stride 68 two of the four overlap on 8 banks (one extra LDS cycle per read).  Stride 72
+//     would have none, and 6 KB more LDS per workgroup than the scan kernel has.
+//   E2: what a lane reads together sits together: two halves {c = 0, 1} and {c = 2, 3} of 256 16-byte entries
+//     (entry p = k1 + 16 t holds the two c of its half), so that stage C is eight 16-byte reads of consecutive
+//     entries by consecutive lanes; the halves start 16 banks apart (8 entries of padding), which spreads the 8-byte
+//     stores of a 16-lane group -- four k1 times four c -- over all 32 banks.
+//   Twiddles the same way: tw1 holds W1024^(l k1) for k1 = 2 j + 1, 2 j + 2 side by side (entry j * 64 + l), tw2 holds
+//     W64^(c t) for t = 2 j + 1, 2 j + 2 side by side in rows of 9 entries per c (the ninth is padding: rows on banks of
+//     their own): eight 16-byte reads per stage instead of fifteen 8-byte ones.
 // E1 and E2 may be the same memory: a wave has read all of E1 before it writes E2 (program order).
+struct alignas(16) c32x2 {
+  c32 a, b;
+};
 constexpr int kRowA = 68;                  // E1[16][68]
-constexpr int kRowC = 260;                 // E2[4][260]
-constexpr int kScratchW = 16 * kRowA;      // c32 entries of scratch per transform (8704 B; 4 * 260 fits too)
-// tw1[k1 * 64 + l] = W1024^(l k1) (k1 < 16, l < 64);  tw2[t * 4 + c] = W64^(c t) (t < 16, c < 4).
+constexpr int kE2Half = 2 * 256 + 8;       // c32 entries from one half of E2 to the other
+constexpr int kE2Len = 2 * kE2Half;        // c32 entries of an E2 (a hand-over buffer of the scan kernel)
+constexpr int kScratchW = 16 * kRowA;      // c32 entries of scratch per transform (8704 B; an E2 fits too)
+static_assert(kE2Len <= kScratchW, "exchange 2 must fit into the exchange area");
+constexpr int kTw1Len = 16 * 64;           // c32 entries of the tables
+constexpr int kTw2Len = 4 * 9 * 2;
+// (index 0 of either table is the factor 1 and is not stored: entry j holds the indices 2 j + 1 and 2 j + 2)
+LT_HD int tw1_index(int k1, int l) { return (((k1 - 1) >> 1) * 64 + l) * 2 + ((k1 - 1) & 1); } // W1024^(l k1), 1 <= k1 < 16, l < 64
+LT_HD int tw2_index(int t, int c) { return (c * 9 + ((t - 1) >> 1)) * 2 + ((t - 1) & 1); }      // W64^(c t), 1 <= t < 16, c < 4
+LT_HD int e2_index(int c, int p) { return (c >> 1) * kE2Half + 2 * p + (c & 1); }
+// place of element l = c + 4 s in a row of E1: s = 2 j and 2 j + 1 side by side, the four c of a j next to each other
+LT_HD int e1_pos(int l) { return ((l >> 3) << 3) | ((l & 3) << 1) | ((l >> 2) & 1); }
 // A stage's twiddles are read before its butterflies (15 values, 30 registers): a wave's LDS reads return in
 // 100-250 cycles while other waves keep the LDS busy, and read group by group after the butterflies that
 // latency was exposed four times per stage (more than half of the stage's time).
 struct Twiddles { c32 w[15]; };
 LT_HD void stageA_twiddles(int l, const c32 *tw1, Twiddles &t)
 {
+  const c32x2 *p = reinterpret_cast<const c32x2 *>(tw1) + l;
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) t.w[k1 - 1] = tw1[k1 * 64 + l];
+  for (int j = 0; j < 8; ++j) {
+    const c32x2 v = p[j * 64];
+    t.w[2 * j] = v.a;                 // k1 = 2 j + 1
+    if (j < 7) t.w[2 * j + 1] = v.b;  // k1 = 2 j + 2
+  }
 }
 LT_HD void stageB_twiddles(int l, const c32 *tw2, Twiddles &t)
 {
+  const c32x2 *p = reinterpret_cast<const c32x2 *>(tw2) + (l & 3) * 9;
 #pragma unroll
-  for (int k = 1; k < 16; ++k) t.w[k - 1] = tw2[k * 4 + (l & 3)];
+  for (int j = 0; j < 8; ++j) {
+    const c32x2 v = p[j];
+    t.w[2 * j] = v.a;
+    if (j < 7) t.w[2 * j + 1] = v.b;
+  }
 }
 template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const Twiddles &t, c32 *e)
 {
   fft16<1, kInv>(v);
   LT_FFT_FENCE;
-  e[l] = v[0];
+  c32 *out = e + e1_pos(l);
+  out[0] = v[0];
 #pragma unroll
   for (int k1 = 1; k1 < 16; ++k1) {
     v[k1] = cmulw<kInv>(v[k1], t.w[k1 - 1]);
-    e[k1 * kRowA + l] = v[k1];
+    out[k1 * kRowA] = v[k1];
   }
 }
 template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32 *tw2, const c32 *e1, c32 *e2)
 {
   const int k1 = l >> 2, c = l & 3;
+  const c32x2 *in = reinterpret_cast<const c32x2 *>(e1 + k1 * kRowA + 2 * c);
 #pragma unroll
-  for (int s = 0; s < 16; ++s) v[s] = e1[k1 * kRowA + c + 4 * s];
+  for (int j = 0; j < 8; ++j) {
+    const c32x2 p = in[4 * j]; // s = 2 j, 2 j + 1
+    v[2 * j] = p.a;
+    v[2 * j + 1] = p.b;
+  }
   Twiddles t;
   stageB_twiddles(l, tw2, t);
   LT_FFT_FENCE;
   fft16<1, kInv>(v);
   LT_FFT_FENCE;
-  e2[c * kRowC + k1] = v[0];
+  c32 *out = e2 + e2_index(c, k1);
+  out[0] = v[0];
 #pragma unroll
   for (int k = 1; k < 16; ++k) {
     v[k] = cmulw<kInv>(v[k], t.w[k - 1]);
-    e2[c * kRowC + k1 + 16 * k] = v[k];
+    out[2 * 16 * k] = v[k]; // entry p = k1 + 16 k
   }
 }
 // (stage A reading its own twiddles: for callers with nothing to overlap the reads with)
@@ -175,10 +215,11 @@ template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const c32 *tw1
 }
 template <bool kInv> LT_HD void fft1024w_stageC(int l, c32 v[16], const c32 *e2)
 {
+  const c32x2 *lo = reinterpret_cast<const c32x2 *>(e2) + l, *hi = reinterpret_cast<const c32x2 *>(e2 + kE2Half) + l;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int p = l + 64 * i;
-    radix4<kInv>(e2[p], e2[kRowC + p], e2[2 * kRowC + p], e2[3 * kRowC + p], v[i], v[i + 4], v[i + 8], v[i + 12]);
+    const c32x2 a = lo[64 * i], b = hi[64 * i];
+    radix4<kInv>(a.a, a.b, b.a, b.b, v[i], v[i + 4], v[i + 8], v[i + 12]);
   }
 }
 

@@ -21,7 +21,7 @@
 // of the hand-over buffer, multiplies the spectrum by its root's filter spectrum (held in registers), transforms
 // back, keeps its root's average and reduces it to the strip's partial result.
 //   workgroup = 12 waves = 3 per SIMD; LDS: 12 exchange areas (102 KB) + 6 hand-over buffers (49 KB) + twiddles
-//   (8.5 KB) = 163 160 of 163 840 bytes
+//   (8.6 KB) = 163 224 of 163 840 bytes
 #pragma once
 #include "lt_scan.h"
 
@@ -119,12 +119,12 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
 {
   constexpr int kScanWaves = scan_waves(kScanGroups), kScanThreads = scan_threads(kScanGroups), kScanWgPerJob = scan_wg_per_job(kScanGroups);
   static_assert(kStrips % kScanGroups == 0, "a job's strips divide evenly among its workgroups");
-  __shared__ v2f E[kScanWaves * fft::kScratchW]; // one exchange area per wave
+  __shared__ __attribute__((aligned(16))) v2f E[kScanWaves * fft::kScratchW]; // one exchange area per wave
   // a forward wave leaves its blocks (two transform stages done) here for the group's root waves, in turn: while
   // they read one, it fills the other
-  __shared__ v2f OUT[kScanGroups][2][4 * fft::kRowC];
-  __shared__ fft::c32 TW1[16 * 64];
-  __shared__ fft::c32 TW2[16 * 4];
+  __shared__ __attribute__((aligned(16))) v2f OUT[kScanGroups][2][fft::kE2Len];
+  __shared__ __attribute__((aligned(16))) fft::c32 TW1[fft::kTw1Len];
+  __shared__ __attribute__((aligned(16))) fft::c32 TW2[fft::kTw2Len];
   __shared__ int sync_ready[kScanGroups][3], sync_taken[kScanGroups][3];
 #ifdef LT_SCAN_PROF
   __shared__ unsigned PROF[kScanWaves][8]; // shader-clock ticks per phase and wave (in LDS: the kernel has no scalar registers to spare)
@@ -156,8 +156,8 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
   const int my_seq = role ? uniform_i32(jp->seq_of_root[root]) : 0;
   const bool active = role == 0 || my_seq >= 0;
 
-  for (int i = tid; i < 16 * 64; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
-  if (tid < 64) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
+  for (int i = tid; i < fft::kTw1Len; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
+  if (tid < fft::kTw2Len) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
   if (tid < kScanGroups * 3) (&sync_ready[0][0])[tid] = (&sync_taken[0][0])[tid] = 0;
 #ifdef LT_SCAN_PROF
   if (tid < kScanWaves * 8) (&PROF[0][0])[tid] = 0u;

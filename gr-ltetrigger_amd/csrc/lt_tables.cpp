@@ -99,15 +99,15 @@ void build_device_tables(DeviceTables *t)
     t->dft128_sin[e] = std::sin(ph);
   }
 
-  for (int k1 = 0; k1 < 16; ++k1)
+  for (int k1 = 1; k1 < 16; ++k1) // (k1 = 0, t = 0: the factor 1, not stored)
     for (int l = 0; l < 64; ++l) {
       const double ph = -2.0 * kPi * (double)(l * k1) / 1024.0;
-      pair_entry(t->fft_tw1[k1 * 64 + l], (float)std::cos(ph), (float)std::sin(ph));
+      pair_entry(t->fft_tw1[fft::tw1_index(k1, l)], (float)std::cos(ph), (float)std::sin(ph));
     }
-  for (int tt = 0; tt < 16; ++tt)
+  for (int tt = 1; tt < 16; ++tt)
     for (int c = 0; c < 4; ++c) {
       const double ph = -2.0 * kPi * (double)(c * tt) / 64.0;
-      pair_entry(t->fft_tw2[tt * 4 + c], (float)std::cos(ph), (float)std::sin(ph));
+      pair_entry(t->fft_tw2[fft::tw2_index(tt, c)], (float)std::cos(ph), (float)std::sin(ph));
     }
   for (int r = 0; r < 3; ++r)
     for (int k = 0; k < 1024; ++k) {

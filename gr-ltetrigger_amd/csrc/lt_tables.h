@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "lt_fft.h" // table geometry
+
 namespace lt {
 
 struct cf32 { float re, im; };
@@ -32,10 +34,11 @@ struct DeviceTables {
   uint32_t sss_s_mask, sss_z_mask, sss_c0_mask[3], sss_c1_mask[3];
   // overlap-save matched filter (csrc/lt_fft.h): the 1024-point spectrum of the zero-padded filter divided by
   // 1024, natural order (element k = lane + 64 reg is what lane `lane` holds in register `reg`), and the
-  // transform's twiddles W1024^(l k1) as [k1][l] (16 x 64), W64^(c t) as [t][c] (16 x 4), (re, im)
+  // transform's twiddles W1024^(l k1) and W64^(c t), (re, im), in the paired layouts the kernels read 16 bytes at a
+  // time (fft::tw1_index, fft::tw2_index; the padding entries of fft_tw2 are zero)
   cf32 pss_spec[3][1024];
-  float fft_tw1[16 * 64][2];
-  float fft_tw2[16 * 4][2];
+  float fft_tw1[fft::kTw1Len][2];
+  float fft_tw2[fft::kTw2Len][2];
 };
 
 void build_device_tables(DeviceTables *t);

@@ -32,16 +32,16 @@ int main()
   std::vector<c32> x(kN);
   if (fread(x.data(), sizeof(c32), kN, stdin) != (size_t)kN) return 1;
   std::vector<c32> X, Y;
-  std::vector<c32> tw1(16 * 64), tw2(16 * 4);
-  for (int k1 = 0; k1 < 16; ++k1)
+  std::vector<c32> tw1(kTw1Len), tw2(kTw2Len);
+  for (int k1 = 1; k1 < 16; ++k1)
     for (int l = 0; l < 64; ++l) {
       const double ph = -2.0 * M_PI * (double)(l * k1) / 1024.0;
-      tw1[k1 * 64 + l] = c32{(float)cos(ph), (float)sin(ph)};
+      tw1[tw1_index(k1, l)] = c32{(float)cos(ph), (float)sin(ph)};
     }
-  for (int t = 0; t < 16; ++t)
+  for (int t = 1; t < 16; ++t)
     for (int c = 0; c < 4; ++c) {
       const double ph = -2.0 * M_PI * (double)(c * t) / 64.0;
-      tw2[t * 4 + c] = c32{(float)cos(ph), (float)sin(ph)};
+      tw2[tw2_index(t, c)] = c32{(float)cos(ph), (float)sin(ph)};
     }
   transform_w<false>(x, X, tw1, tw2);
   fwrite(X.data(), sizeof(c32), kN, stdout);
