@@ -348,20 +348,24 @@ def main():
             "cell_id_match_rate": match_rate,
             "realtime_factor": round(value * 1e6 / (world * n_ch * FS), 2),
             # algorithmic bytes = 8 B per input sample, whatever a kernel spills on top.
-            # achieved = those bytes / the dominant stage's time (the stage with the largest measured duration)
+            # achieved / frac = those bytes / the wall time of a step of the timed region (= `value` x 8 B: reset, every launch of
+            # the run, the gaps between runs); `device_*` = the same against the run's launches alone (first to last, by the
+            # library's HIP events on the launch stream); `stage_*` = against the dominant stage alone (the scan rounds:
+            # lt_plan_kernel + lt_scan_kernel + lt_resolve_kernel launches).
             "roofline": {
                 "bound": "hbm",
-                "kernel": dom["stage"],
-                "kernel_ms": dom["ms"],
+                "kernel": "lt_scan_kernel (dominant; stage '%s' = %s)" % (dom["stage"], " + ".join(dom["kernels"])),
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "achieved": round(algo_bytes / (dom["ms"] * 1e-3) / 1e9, 2),
+                "achieved": round(algo_bytes / (elapsed / args.steps) / 1e9, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(algo_bytes / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                # the whole path (all stages of a step, device time) against the same 8 B per sample
-                "path_ms": round(kernel_ms, 4),
-                "path_achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 2),
-                "path_frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frac": round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                "device_ms": round(kernel_ms, 4),
+                "device_achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 2),
+                "device_frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "stage_ms": dom["ms"],
+                "stage_achieved": round(algo_bytes / (dom["ms"] * 1e-3) / 1e9, 2),
+                "stage_frac": round(algo_bytes / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 # HBM bytes per launch from the PMC counters of a profiled run of this same command
                 "traffic": traffic_total,
                 "traffic_ratio": round(traffic_total / algo_bytes, 3) if traffic_total else None,
@@ -396,7 +400,22 @@ def load_traffic():
     k = t.get("kernels", {})
     if "lt_scan_kernel" not in k:
         return None, "profiles/traffic.json predates the current kernels"
+    if t.get("kernel_source_sha16") != kernel_source_sha16():
+        return None, ("profiles/traffic.json was taken with other kernel sources (its kernel_source_sha16 "
+                      f"{t.get('kernel_source_sha16')} != {kernel_source_sha16()}): re-run tools/pmc_traffic.sh")
     return k, f"profiles/traffic.json ({t.get('taken', 'undated')}; {t.get('method', '')})"
+
+
+def kernel_source_sha16():
+    """Hash of the device sources (gr-ltetrigger_amd/csrc): ties profiles/traffic.json to the kernels it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gr-ltetrigger_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def end_to_end(torch, lt, iq, n_ch, n, device):

@@ -66,6 +66,33 @@ template <bool kConjB> LT_HD c32 cmulw(c32 a, c32 w)
 #endif
 }
 
+// Two such products at once, the two v_pk_mul first: a v_pk_fma that takes the product written by the instruction
+// right before it as its addend costs a wait state (the compiler pads the pair with an s_nop) and, in a wave that is
+// alone on its SIMD, the full latency of the multiply.
+template <bool kConjB> LT_HD void cmulw2(c32 &a0, c32 w0, c32 &a1, c32 w1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  c32 p0, p1;
+  if (kConjB)
+    asm("v_pk_mul_f32 %[p0], %[a0], %[w0] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %[p1], %[a1], %[w1] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %[a0], %[a0], %[w0], %[p0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[a1], %[a1], %[w1], %[p1] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [p0] "=&v"(p0), [p1] "=&v"(p1)
+        : [w0] "v"(w0), [w1] "v"(w1));
+  else
+    asm("v_pk_mul_f32 %[p0], %[a0], %[w0] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %[p1], %[a1], %[w1] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %[a0], %[a0], %[w0], %[p0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %[a1], %[a1], %[w1], %[p1] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : [a0] "+v"(a0), [a1] "+v"(a1), [p0] "=&v"(p0), [p1] "=&v"(p1)
+        : [w0] "v"(w0), [w1] "v"(w1));
+#else
+  a0 = cmulw<kConjB>(a0, w0);
+  a1 = cmulw<kConjB>(a1, w1);
+#endif
+}
+
 // radix-4 butterfly, forward (W4 = -j) or inverse (W4 = +j)
 template <bool kInv> LT_HD void radix4(c32 a, c32 b, c32 c, c32 d, c32 &y0, c32 &y1, c32 &y2, c32 &y3)
 {
@@ -92,15 +119,24 @@ template <int S, bool kInv> LT_HD void fft16(c32 *v)
   const c32 w4 = cw<kInv>(c32{0.f, -1.f});
   const c32 w6 = cw<kInv>(c32{-0.70710678118654752f, -0.70710678118654752f});
   const c32 w9 = cw<kInv>(c32{-0.92387953251128674f, 0.38268343236508977f});
-  t[4 * 1 + 1] = cmulc(t[4 * 1 + 1], w1);
-  t[4 * 1 + 2] = cmulc(t[4 * 1 + 2], w2);
-  t[4 * 1 + 3] = cmulc(t[4 * 1 + 3], w3);
-  t[4 * 2 + 1] = cmulc(t[4 * 2 + 1], w2);
-  t[4 * 2 + 2] = cmulc(t[4 * 2 + 2], w4);
-  t[4 * 2 + 3] = cmulc(t[4 * 2 + 3], w6);
-  t[4 * 3 + 1] = cmulc(t[4 * 3 + 1], w3);
-  t[4 * 3 + 2] = cmulc(t[4 * 3 + 2], w6);
-  t[4 * 3 + 3] = cmulc(t[4 * 3 + 3], w9);
+  // (three at a time: the products a.y * (j w) first, then the fused a.x * w + product -- a packed FMA whose addend
+  // was written by the instruction right before it costs a wait state)
+  const int idx[9] = {5, 6, 7, 9, 10, 11, 13, 14, 15};
+  const c32 ww[9] = {w1, w2, w3, w2, w4, w6, w3, w6, w9};
+#pragma unroll
+  for (int g = 0; g < 9; g += 3) {
+    c32 q[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const c32 a = t[idx[g + i]], ayy = {a.y, a.y}, jw = {-ww[g + i].y, ww[g + i].x};
+      q[i] = ayy * jw;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const c32 a = t[idx[g + i]], axx = {a.x, a.x};
+      t[idx[g + i]] = __builtin_elementwise_fma(axx, ww[g + i], q[i]);
+    }
+  }
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1)
     radix4<kInv>(t[4 * k1 + 0], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3], v[S * k1], v[S * (k1 + 4)],
@@ -176,10 +212,13 @@ template <bool kInv> LT_HD void fft1024w_stageA(int l, c32 v[16], const Twiddles
   LT_FFT_FENCE;
   c32 *out = e + e1_pos(l);
   out[0] = v[0];
+  v[1] = cmulw<kInv>(v[1], t.w[0]);
+  out[kRowA] = v[1];
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) {
-    v[k1] = cmulw<kInv>(v[k1], t.w[k1 - 1]);
+  for (int k1 = 2; k1 < 16; k1 += 2) {
+    cmulw2<kInv>(v[k1], t.w[k1 - 1], v[k1 + 1], t.w[k1]);
     out[k1 * kRowA] = v[k1];
+    out[(k1 + 1) * kRowA] = v[k1 + 1];
   }
 }
 template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32 *tw2, const c32 *e1, c32 *e2)
@@ -199,10 +238,13 @@ template <bool kInv> LT_HD void fft1024w_stageB(int l, c32 v[16], const c32 *tw2
   LT_FFT_FENCE;
   c32 *out = e2 + e2_index(c, k1);
   out[0] = v[0];
+  v[1] = cmulw<kInv>(v[1], t.w[0]);
+  out[2 * 16] = v[1]; // entry p = k1 + 16 k
 #pragma unroll
-  for (int k = 1; k < 16; ++k) {
-    v[k] = cmulw<kInv>(v[k], t.w[k - 1]);
-    out[2 * 16 * k] = v[k]; // entry p = k1 + 16 k
+  for (int k = 2; k < 16; k += 2) {
+    cmulw2<kInv>(v[k], t.w[k - 1], v[k + 1], t.w[k]);
+    out[2 * 16 * k] = v[k];
+    out[2 * 16 * (k + 1)] = v[k + 1];
   }
 }
 // (stage A reading its own twiddles: for callers with nothing to overlap the reads with)

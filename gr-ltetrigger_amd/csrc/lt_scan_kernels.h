@@ -597,7 +597,7 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
     const int nb = n_bc - blk < 64 ? n_bc - blk : 64;
     WindowResult wr;
     wr.peak_pos = 0; wr.peak_value = 0.f; wr.psr = 0.f; wr.exact = true;
-    if (lane < nb) wr = resolve_window(a.parts + ((int64_t)chain * kScanMaxRound + blk + lane) * kStrips);
+    if (lane < nb) wr = resolve_window_global(a.parts + ((int64_t)chain * kScanMaxRound + blk + lane) * kStrips);
     // ---- an idle chain (lib/pss_impl.cc:134-135: a miss with score 0 changes nothing but d_psr, the ring and the
     // position): all the misses up to the first window that fires, one lane each
     int k0 = 0;

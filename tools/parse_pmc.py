@@ -9,6 +9,8 @@ import os
 import sys
 
 root = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha16  # noqa: E402  (the hash bench.py checks before it quotes these numbers)
 
 
 RUNS = int(sys.argv[2]) if len(sys.argv) > 2 else 3  # lt_batch_run calls per profiled process (probe.py --reps)
@@ -57,6 +59,7 @@ if fd:
         print(f"calibration: decimator writes {true_write} B = {wd} WRITE units -> {bytes_per_write_unit:.1f} B/unit")
     res = {"kernels": {}, "bytes_per_fetch_unit": bytes_per_fetch_unit, "bytes_per_write_unit": bytes_per_write_unit,
            "taken": __import__("datetime").date.today().isoformat(),
+           "kernel_source_sha16": kernel_source_sha16(),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on tools/probe.py --mode mix (the bench "
                      "workload), summed over the launches of a run; units calibrated on lt_decim_kernel (known 983.04 MB "
                      "read with 8 B/lane loads, 122.88 MB written)"}
