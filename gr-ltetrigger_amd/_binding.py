@@ -42,9 +42,9 @@ EXPORTS = [
     "lt_sync_set_cp", "lt_sync_get_cp_len", "lt_sync_get_cp_metrics", "lt_sss_m0m1_partial",
     "lt_sss_N_id_1", "lt_sync_get_cell_id",
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
-    "lt_batch_run", "lt_batch_collect", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
+    "lt_batch_run", "lt_batch_collect", "lt_batch_collect_previous", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
     "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms", "lt_batch_push",
-    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_debug_hold_records", "lt_batch_set_scan_groups",
+    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_debug_hold_records", "lt_batch_set_phase_timing", "lt_batch_set_scan_groups",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
 
@@ -125,8 +125,10 @@ def lib():
     L.lt_batch_set_scan_segments.argtypes = [vp, i32, i32]
     L.lt_batch_set_overlap.argtypes = [vp, i32]
     L.lt_batch_debug_hold_records.argtypes = [vp, i32]
+    L.lt_batch_set_phase_timing.argtypes = [vp, i32]
     L.lt_batch_set_scan_groups.argtypes = [vp, i32]
     L.lt_batch_collect.argtypes = [vp, vp, i64, vp]
+    L.lt_batch_collect_previous.argtypes = [vp, vp, i64, vp]
     L.lt_batch_record_capacity.argtypes = [i64]
     L.lt_batch_record_capacity.restype = i64
     L.lt_batch_enable_halfframes.argtypes = [vp, i64]
@@ -340,6 +342,10 @@ class Batch:
         """Per-record kernels of a device run beside the next run's scan rounds (lt_batch_set_overlap)."""
         _check(lib().lt_batch_set_overlap(self._h, 1 if on else 0), "lt_batch_set_overlap")
 
+    def set_phase_timing(self, level):
+        """HIP events of a run: 2 = around it and between its stages, 1 = around it, 0 = none (lt_batch_set_phase_timing)."""
+        _check(lib().lt_batch_set_phase_timing(self._h, int(level)), "lt_batch_set_phase_timing")
+
     def debug_hold_records(self, microseconds):
         """Diagnostics: every run's per-record kernels start this much later (lt_batch_debug_hold_records)."""
         _check(lib().lt_batch_debug_hold_records(self._h, int(microseconds)), "lt_batch_debug_hold_records")
@@ -383,6 +389,15 @@ class Batch:
         counts = np.zeros(nch, np.int64)
         _check(lib().lt_batch_collect(self._h, recs.ctypes.data_as(C.c_void_p), self.rec_cap,
                                       counts.ctypes.data_as(C.c_void_p)), "lt_batch_collect")
+        return [recs[c, : counts[c]] for c in range(nch)]
+
+    def collect_previous(self):
+        """Overlap mode: the records of the run before the last one (lt_batch_collect_previous)."""
+        nch = self.n_channels * 3
+        recs = np.zeros((nch, self.rec_cap), RECORD_DTYPE)
+        counts = np.zeros(nch, np.int64)
+        _check(lib().lt_batch_collect_previous(self._h, recs.ctypes.data_as(C.c_void_p), self.rec_cap,
+                                               counts.ctypes.data_as(C.c_void_p)), "lt_batch_collect_previous")
         return [recs[c, : counts[c]] for c in range(nch)]
 
     def halfframes(self, chain):

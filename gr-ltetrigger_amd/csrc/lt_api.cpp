@@ -166,6 +166,9 @@ struct lt_batch {
   hipEvent_t ev[kPhaseRing][4] = {};
   uint64_t n_runs = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; // = ev[last run][0], [3]
+  int phase_timing = 2;            // lt_batch_set_phase_timing: 2 = events between the stages of a run, 1 = around it, 0 = none
+  bool ev_phased[kPhaseRing] = {}; // the run in this slot recorded the stage events
+  bool ev_timed = false;           // the last run recorded its first and last event
   bool ran = false;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
@@ -181,6 +184,8 @@ struct lt_batch {
   int records_delay_us = 0;        // lt_batch_debug_hold_records
   lt_record *cur_recs = nullptr;   // the set the last run wrote
   int *cur_count = nullptr;
+  uint64_t set_run[2] = {0, 0};    // 1 + the number of the run whose records set 0 / 1 holds (0: none)
+  hipStream_t copy = nullptr;      // lt_batch_collect_previous: its copies, beside the run in flight
 };
 
 struct lt_decim {
@@ -579,6 +584,7 @@ void lt_batch_free(lt_batch *b)
       if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->rec_done)
     if (e) (void)hipEventDestroy(e);
+  if (b->copy) (void)hipStreamDestroy(b->copy);
   if (b->side) (void)hipStreamDestroy(b->side);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -648,14 +654,14 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   }
   if (ov && b->rec_done_valid[set]) HIP_TRY(hipStreamWaitEvent(s, b->rec_done[set], 0)); // this set's last user, two runs ago
   if (b->pending_reset) {
+    int *count = set ? b->d_count_b : b->d_count; // (this set's record counts: cleared by the same launch)
     if (ov) { // the per-record kernels' members on their stream, behind the previous run's
-      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 1, s));
-      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 2, b->side));
+      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 1, count, s));
+      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 2, nullptr, b->side));
       b->side_busy = true;
     } else {
-      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 3, s));
+      HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 3, count, s));
     }
-    HIP_TRY(hipMemsetAsync(set ? b->d_count_b : b->d_count, 0, sizeof(int) * nchains, s));
     b->pending_reset = false;
   }
   if (restart) {
@@ -706,14 +712,19 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.cp_scratch = b->d_cp;
   R.records_delay_us = b->records_delay_us;
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
-  R.ev_scan_done = b->ev[slot][1];
-  R.ev_chain_done = b->ev[slot][2];
+  // (an event between two launches costs the stream ~5 us: the stage events are there for lt_batch_phase_ms only --
+  // and the one behind the per-chain kernel for the per-record kernels' stream in overlap mode)
+  R.ev_scan_done = b->phase_timing >= 2 ? b->ev[slot][1] : nullptr;
+  R.ev_chain_done = (b->phase_timing >= 2 || ov) ? b->ev[slot][2] : nullptr;
+  b->ev_phased[slot] = b->phase_timing >= 2;
+  b->ev_timed = b->phase_timing >= 1;
   b->ev0 = b->ev[slot][0];
   b->ev1 = b->ev[slot][3];
   b->n_runs++;
-  HIP_TRY(hipEventRecord(b->ev0, s));
+  b->set_run[set] = b->n_runs;
+  if (b->ev_timed) HIP_TRY(hipEventRecord(b->ev0, s));
   HIP_TRY(lt::launch_run(R, s, ov ? b->side : nullptr));
-  HIP_TRY(hipEventRecord(b->ev1, ov ? b->side : s));
+  if (b->ev_timed) HIP_TRY(hipEventRecord(b->ev1, ov ? b->side : s));
   if (ov) {
     HIP_TRY(hipEventRecord(b->rec_done[set], b->side));
     b->rec_done_valid[set] = true;
@@ -751,6 +762,8 @@ int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4])
   int rc = use_device(b->device);
   if (rc) return rc;
   const int slot = (int)((b->n_runs - 1 - (uint64_t)runs_back) % lt_batch::kPhaseRing);
+  if (!b->ev_phased[slot])
+    return fail(LT_ERROR, "lt_batch_phase_ms: that run was made with the stage events off (lt_batch_set_phase_timing)");
   hipEvent_t *e = b->ev[slot];
   HIP_TRY(hipEventSynchronize(e[3]));
   ms[1] = 0.f;
@@ -764,6 +777,7 @@ int lt_batch_last_kernel_ms(lt_batch *b, float *ms)
 {
   if (!b || !ms) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
   if (!b->ran) return fail(LT_ERROR, "no run yet");
+  if (!b->ev_timed) return fail(LT_ERROR, "lt_batch_last_kernel_ms: the last run was made without events (lt_batch_set_phase_timing 0)");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipEventSynchronize(b->ev1));
   HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
@@ -794,6 +808,36 @@ int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_
     if (n > 0)
       memcpy(recs + c * (size_t)cap_per_chain, b->h_recs.data() + c * (size_t)b->rec_cap,
              sizeof(lt_record) * (size_t)n);
+  }
+  return LT_OK;
+}
+
+int lt_batch_collect_previous(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts)
+{
+  if (!b || !counts || (cap_per_chain > 0 && !recs)) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (b->n_runs < 2) return fail(LT_ERROR, "lt_batch_collect_previous: fewer than two runs so far");
+  // the run before the last one wrote the other set if and only if both were overlapped runs
+  const int set = b->cur_recs == b->d_recs ? 1 : 0;
+  if (!b->d_recs_b || b->set_run[set] != b->n_runs - 1)
+    return fail(LT_ERROR, "lt_batch_collect_previous: the last run has overwritten the records of the one before "
+                          "(two sets of records exist only between overlapped runs, lt_batch_set_overlap)");
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->copy) HIP_TRY(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+  // that run's per-record kernels are through when its event is (the last run's may still be under way)
+  HIP_TRY(hipStreamWaitEvent(b->copy, b->rec_done[set], 0));
+  const size_t nchains = (size_t)b->n_channels * 3;
+  b->h_count.resize(nchains);
+  b->h_recs.resize(nchains * (size_t)b->rec_cap);
+  HIP_TRY(hipMemcpyAsync(b->h_count.data(), set ? b->d_count_b : b->d_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, b->copy));
+  HIP_TRY(hipMemcpyAsync(b->h_recs.data(), set ? b->d_recs_b : b->d_recs, sizeof(lt_record) * b->h_recs.size(),
+                         hipMemcpyDeviceToHost, b->copy));
+  HIP_TRY(hipStreamSynchronize(b->copy));
+  for (size_t c = 0; c < nchains; ++c) {
+    int64_t n = b->h_count[c];
+    counts[c] = n;
+    if (n > cap_per_chain) n = cap_per_chain;
+    if (n > 0)
+      memcpy(recs + c * (size_t)cap_per_chain, b->h_recs.data() + c * (size_t)b->rec_cap, sizeof(lt_record) * (size_t)n);
   }
   return LT_OK;
 }
@@ -868,6 +912,13 @@ int lt_batch_set_overlap(lt_batch *b, int on)
     }
   }
   b->overlap = on;
+  return LT_OK;
+}
+
+int lt_batch_set_phase_timing(lt_batch *b, int level)
+{
+  if (!b || level < 0 || level > 2) return fail(LT_ERROR_INVALID_INPUTS, "phase timing must be 0, 1 or 2");
+  b->phase_timing = level;
   return LT_OK;
 }
 

@@ -274,11 +274,18 @@ __global__ __launch_bounds__(64) void lt_cfo_ring_kernel(CpArgs a)
     part += lane_xor_d<8>(part); part += lane_xor_d<16>(part); part += lane_xor_d<32>(part);
     acc = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)), __builtin_amdgcn_readfirstlane(__double2loint(part)));
   }
+  uint32_t flags_n = lane < count ? recs[lane].flags : 0u;
+  float cfo_n = lane < count ? recs[lane].cfo : 0.f; // (fetched with the flags, and a block ahead)
   for (int base = 0; base < count; base += 64) {
     const int i = base + lane;
-    const uint32_t flags = i < count ? recs[i].flags : 0u;
+    const uint32_t flags = flags_n;
     const bool is_ran = (flags & LT_F_SSS_RAN) != 0;
-    const float c = is_ran ? recs[i].cfo : 0.f;
+    const float c = is_ran ? cfo_n : 0.f;
+    {
+      const int in = i + 64;
+      flags_n = in < count ? recs[in].flags : 0u;
+      cfo_n = in < count ? recs[in].cfo : 0.f;
+    }
     const unsigned long long ran = __ballot(is_ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
     if (!ran && !lost) continue;
     // ---- the 64 records at once.  While the exponent window holds for every entry up to the last of these
@@ -446,14 +453,22 @@ __global__ __launch_bounds__(64) void lt_cp_scan_kernel(CpArgs a)
   lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
   const CpMetrics *cm = a.metrics + (int64_t)chain * a.rec_cap;
   const int count = a.rec_count[chain];
+  // (a record's flags and its metrics are fetched together, and the next 64 records' while this block is walked: the
+  // scratch entry of a record that is no tracked half-frame holds whatever an earlier run left there and is not looked at)
+  uint32_t flags_n = lane < count ? recs[lane].flags : 0u;
+  CpMetrics c_n = lane < count ? cm[lane] : CpMetrics{};
   for (int base = 0; base < count; base += 64) {
     const int i = base + lane;
     const bool valid = i < count;
-    const uint32_t flags = valid ? recs[i].flags : 0u;
+    const uint32_t flags = flags_n;
     const bool ran = (flags & LT_F_SSS_RAN) != 0;
-    CpMetrics c;
-    c.m[0] = c.m[1] = c.r[0] = c.r[1] = 0.f;
-    if (ran) c = cm[i];
+    CpMetrics c = c_n;
+    if (!ran) c.m[0] = c.m[1] = c.r[0] = c.r[1] = 0.f;
+    {
+      const int in = i + 64;
+      flags_n = in < count ? recs[in].flags : 0u;
+      if (in < count) c_n = cm[in];
+    }
     const float in_norm = cp_avg_input(c.m[0]), in_ext = cp_avg_input(c.m[1]);
     const unsigned long long run = __ballot(ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
     float my_norm = m_norm_avg, my_ext = m_ext_avg; // state as of this lane's record
@@ -827,8 +842,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
 // lt_batch_reset: the chains back to their constructor state.  The members only the per-record kernels
 // touch (CFO ring, CP averages) are cleared separately, so that with lt_batch_set_overlap they can be cleared on the
 // stream those kernels run on, behind the previous run's.  parts: 1 = everything else, 2 = those members, 3 = all.
-__global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int parts)
+__global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int parts, int *rec_count)
 {
+  if (rec_count && threadIdx.x == 0) rec_count[blockIdx.x] = 0;
   uint32_t *w = reinterpret_cast<uint32_t *>(state + blockIdx.x);
   // everything in front of the three average buffers; those are not cleared but declared zero (ema_zero = 2)
   constexpr int n = (int)(offsetof(ChainState, avg) / 4);
@@ -841,9 +857,9 @@ __global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int pa
     if (parts & (rec ? 2 : 1)) w[i] = i == i_zero ? 2u : 0u;
   }
 }
-hipError_t launch_reset(void *state, int n_chains, int parts, hipStream_t stream)
+hipError_t launch_reset(void *state, int n_chains, int parts, int *rec_count, hipStream_t stream)
 {
-  hipLaunchKernelGGL(lt_reset_kernel, dim3((unsigned)n_chains), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), parts);
+  hipLaunchKernelGGL(lt_reset_kernel, dim3((unsigned)n_chains), dim3(256), 0, stream, reinterpret_cast<ChainState *>(state), parts, rec_count);
   return hipGetLastError();
 }
 

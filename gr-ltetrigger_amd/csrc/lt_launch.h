@@ -42,7 +42,7 @@ struct RunLaunch {
   int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
   int scan_groups = 0;        // strips per scan workgroup: 1, 2 or 3; 0 = chosen from n_channels and n_cus
   int n_cus = 0;              // compute units of the device (0: 256)
-  int extra_rounds = 2;       // rounds beyond what an idle chain needs (a chain that fires spends a few on its way to tracking)
+  int extra_rounds = 1;       // rounds beyond what an idle chain needs (two empty launches, 9 us, when nothing is left to do)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the two work lists
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr; // (required when the per-record kernels go to a stream of their own)
@@ -56,7 +56,7 @@ struct RunLaunch {
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t records_stream = nullptr);
 // lt_batch_reset: chain state back to the constructor's; parts: 1 = all but the members only the per-record kernels
 // touch, 2 = those, 3 = both
-hipError_t launch_reset(void *state, int n_chains, int parts, hipStream_t stream);
+hipError_t launch_reset(void *state, int n_chains, int parts, int *rec_count, hipStream_t stream); // rec_count: [n_chains] to clear, or null
 int call_reach();
 int scan_job_bytes();
 int scan_parts_bytes_per_chain();

@@ -217,6 +217,11 @@ int lt_batch_push(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sa
 /* Wait for the last run; copy records out: recs = [n_channels*3][cap_per_chain],
  * counts = [n_channels*3]; chain index = channel*3 + N_id_2. */
 int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts);
+/* With overlap on, the records of the run BEFORE the last one (the two sets of records take turns): waits for that
+ * run's per-record kernels only and copies on a stream of its own, so that  run(k + 1); collect_previous() -> run k's
+ * records  keeps a run in flight all the time and still hands every run's records out.  Fails when the run before
+ * the last one was not an overlapped run (its records have been overwritten). */
+int lt_batch_collect_previous(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts);
 /* Upper bound on records per chain and run for chunks of n_samples (a call consumes >= 8640 samples; a chunk
  * may also finish calls left over from the one before). */
 int64_t lt_batch_record_capacity(int64_t n_samples);
@@ -232,6 +237,10 @@ int lt_batch_last_kernel_ms(lt_batch *b, float *ms);
  * ms[0] = plan + grid scan + resolve (all segments), ms[1] = 0, ms[2] = per-chain kernel, ms[3] = the
  * per-record kernels (CP length, SSS) and the history copy. */
 int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4]);
+/* HIP events of a run: level 2 (default) = around the run and between its stages (what lt_batch_phase_ms reads),
+ * 1 = around the run only (lt_batch_last_kernel_ms works, lt_batch_phase_ms fails for such a run), 0 = none (both
+ * fail).  Every event costs the run's stream about 5 us of idle time. */
+int lt_batch_set_phase_timing(lt_batch *b, int level);
 
 /* ------------------------------------------------------------------ decimating FIR */
 /* gnuradio.filter.rational_resampler_ccc(interpolation=1, decimation=N) with its default taps

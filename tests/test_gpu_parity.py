@@ -375,6 +375,28 @@ def test_phase_timers(lt):
     assert b.phase_ms(1)[0] > 0  # the previous run is still on record
     with pytest.raises(RuntimeError):
         b.phase_ms(8)
+    # without the stage events: same records, the run's own time still there, the stage times refused for that run only
+    want = [r.copy() for r in b.collect()]
+    b.set_phase_timing(1)
+    b.run_host(iq)
+    assert b.last_kernel_ms() > 0
+    with pytest.raises(RuntimeError):
+        b.phase_ms(0)
+    assert b.phase_ms(1)[0] > 0
+    b.set_phase_timing(0)
+    b.run_host(iq)
+    with pytest.raises(RuntimeError):
+        b.last_kernel_ms()
+    # (the state carries over from run to run: compare with a fresh batch run as often)
+    b2 = lt.Batch(1, iq.shape[1])
+    b2.run_host(iq)
+    b2.set_mode(0)
+    b2.run_host(iq)
+    b2.run_host(iq)
+    b2.run_host(iq)
+    for g, w in zip(b.collect(), b2.collect()):
+        assert g.tobytes() == w.tobytes()
+    assert len(want) == 3
 
 
 def test_streaming_chunks_give_the_single_run_records(lt, oracle, frames_192):
@@ -479,6 +501,26 @@ def test_overlap_gives_the_same_records(lt, oracle, frames_192):
     last = run(True, False)
     for c in range(18):
         assert last[0][c].tobytes() == ref[-1][c].tobytes(), f"chain {c} (collected at the end only)"
+    # a run in flight all the time and every run's records handed out all the same: run k + 1 is enqueued, then run k's
+    # records are fetched (lt_batch_collect_previous); the last run's with lt_batch_collect
+    bt = lt.Batch(6, n)
+    bt.set_overlap(True)
+    with pytest.raises(RuntimeError):
+        bt.collect_previous()
+    behind = []
+    for i, k in enumerate(seq):
+        bt.run_device(torch.view_as_real(bufs[k]).data_ptr(), n, s.cuda_stream)
+        if i > 0:
+            behind.append([r.copy() for r in bt.collect_previous()])
+    behind.append([r.copy() for r in bt.collect()])
+    for i in range(len(ref)):
+        for c in range(18):
+            assert behind[i][c].tobytes() == ref[i][c].tobytes(), f"run {i} chain {c} (collected one run behind)"
+    bt.set_overlap(False)
+    bt.run_device(torch.view_as_real(bufs[0]).data_ptr(), n, s.cuda_stream)
+    bt.run_device(torch.view_as_real(bufs[1]).data_ptr(), n, s.cuda_stream)
+    with pytest.raises(RuntimeError):  # one set of records without overlap: the run before the last is gone
+        bt.collect_previous()
     # and the first run is the oracle's
     want = oracle.batch_run(a, nthreads=8)
     for c in range(18):
