@@ -294,6 +294,7 @@ def main():
                        "ms_per_step": round(dt_ov / args.steps * 1e3, 4), "records_identical": bool(same_ov),
                        "what": "lt_batch_set_overlap(1): a step's per-record kernels (CFO, CP, SSS) on a second, low-priority stream "
                                "beside the next step's scan rounds; same steps, every step's records complete inside the timed region"}
+    cache_stats = batch.cache_stats()
     found = cells_found(lt, recs, n_ch)
     ok = sum(1 for c in range(n_ch)
              if found[c] == (set() if expect[c] < 0 else {int(expect[c])}))
@@ -356,6 +357,7 @@ def main():
                 "sharding": "independent channels per rank, no collective on the data path",
             },
             "cell_id_match_rate": match_rate,
+            "window_cache": dict(zip(("windows_listed", "searches_cached", "searches_transformed", "chains_waiting", "moved_off_grid", "reruns_cached", "reruns_transformed"), cache_stats)),
             "realtime_factor": round(value * 1e6 / (world * n_ch * FS), 2),
             # algorithmic bytes = 8 B per input sample, whatever a kernel spills on top.
             # achieved / frac = those bytes / the wall time of a step of the timed region (= `value` x 8 B: reset, every launch of

@@ -44,7 +44,7 @@ EXPORTS = [
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_collect_previous", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
     "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms", "lt_batch_push",
-    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_debug_hold_records", "lt_batch_set_phase_timing", "lt_batch_set_scan_groups",
+    "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_debug_hold_records", "lt_batch_set_phase_timing", "lt_batch_set_window_cache", "lt_batch_cache_stats", "lt_batch_set_scan_groups",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
 
@@ -126,6 +126,8 @@ def lib():
     L.lt_batch_set_overlap.argtypes = [vp, i32]
     L.lt_batch_debug_hold_records.argtypes = [vp, i32]
     L.lt_batch_set_phase_timing.argtypes = [vp, i32]
+    L.lt_batch_set_window_cache.argtypes = [vp, i32]
+    L.lt_batch_cache_stats.argtypes = [vp, vp]
     L.lt_batch_set_scan_groups.argtypes = [vp, i32]
     L.lt_batch_collect.argtypes = [vp, vp, i64, vp]
     L.lt_batch_collect_previous.argtypes = [vp, vp, i64, vp]
@@ -341,6 +343,16 @@ class Batch:
     def set_overlap(self, on):
         """Per-record kernels of a device run beside the next run's scan rounds (lt_batch_set_overlap)."""
         _check(lib().lt_batch_set_overlap(self._h, 1 if on else 0), "lt_batch_set_overlap")
+
+    def set_window_cache(self, on):
+        """Lag metrics of the per-chain kernel's windows formed in bulk (lt_batch_set_window_cache)."""
+        _check(lib().lt_batch_set_window_cache(self._h, 1 if on else 0), "lt_batch_set_window_cache")
+
+    def cache_stats(self):
+        """(windows asked for, cached searches, uncached searches of pass 1, chains that waited, hits that moved one off its grid)."""
+        v = np.zeros(7, np.int64)
+        _check(lib().lt_batch_cache_stats(self._h, v.ctypes.data_as(C.c_void_p)), "lt_batch_cache_stats")
+        return tuple(int(x) for x in v)
 
     def set_phase_timing(self, level):
         """HIP events of a run: 2 = around it and between its stages, 1 = around it, 0 = none (lt_batch_set_phase_timing)."""

@@ -150,6 +150,10 @@ struct lt_batch {
   void *d_jobs = nullptr;    // grid scan: ScanJob[n_channels*3]
   int *d_njobs = nullptr;
   void *d_parts = nullptr;   // grid scan: the partial results of a round, per chain
+  void *d_cache = nullptr;   // window cache: cache_slots x cache_slot_bytes()
+  void *d_slot_owner = nullptr;
+  int cache_slots = 0;
+  int use_cache = 1;         // lt_batch_set_window_cache
   void *d_cp = nullptr;      // per-record scratch (CP metrics, work list), [n_channels*3][rec_cap] x per_record_scratch_bytes()
   lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
   int hist_sel = 0;
@@ -551,6 +555,13 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int) * (size_t)lt::scan_counter_ints());
   if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::scan_parts_bytes_per_chain() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)lt::per_record_scratch_bytes() * nchains * (size_t)b->rec_cap);
+  {
+    // window cache: room for every chain's windows of a run, up to 16384 of them (43 KB each)
+    const int64_t per_chain = std::min<int64_t>(max_samples / LT_HALF_FRAME_LEN + 2, lt::cache_max_per_chain());
+    b->cache_slots = (int)std::min<int64_t>((int64_t)nchains * per_chain, 16384);
+    if (e == hipSuccess) e = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
+    if (e == hipSuccess) e = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
+  }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
@@ -575,7 +586,7 @@ void lt_batch_free(lt_batch *b)
   (void)hipSetDevice(b->device);
   if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
   if (b->side) (void)hipStreamSynchronize(b->side);
-  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1],
+  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1], b->d_cache, b->d_slot_owner,
                   b->d_recs_b, b->d_count_b};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
@@ -710,6 +721,9 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.scan_groups = b->scan_groups;
   R.n_cus = b->n_cus;
   R.cp_scratch = b->d_cp;
+  R.cache = b->use_cache ? b->d_cache : nullptr;
+  R.slot_owner = b->d_slot_owner;
+  R.slot_cap = b->cache_slots;
   R.records_delay_us = b->records_delay_us;
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
   // (an event between two launches costs the stream ~5 us: the stage events are there for lt_batch_phase_ms only --
@@ -912,6 +926,25 @@ int lt_batch_set_overlap(lt_batch *b, int on)
     }
   }
   b->overlap = on;
+  return LT_OK;
+}
+
+int lt_batch_cache_stats(lt_batch *b, int64_t stats[7])
+{
+  if (!b || !stats) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (!b->ran) return fail(LT_ERROR, "no run yet");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  int v[7];
+  HIP_TRY(hipMemcpy(v, b->d_njobs + lt::cache_counter_index(), sizeof v, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 7; ++i) stats[i] = v[i];
+  return LT_OK;
+}
+
+int lt_batch_set_window_cache(lt_batch *b, int on)
+{
+  if (!b || (on != 0 && on != 1)) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0 or 1");
+  b->use_cache = on;
   return LT_OK;
 }
 

@@ -44,7 +44,19 @@ struct ChainArgs {
   int track_every;
   int2 *list;          // work list of the per-record kernels: (chain, record) of every tracked half-frame of the run
   int *list_count;
+  // ---- window cache (lt_metric_kernel below).  pass 0: a chain with many searches ahead of it asks for the lag
+  // metric of its coming windows and leaves the rest to pass 1; pass 1: every chain runs to the end of the chunk,
+  // taking the lag metric of a window from the cache where it is there.  cache == null: one pass, no cache.
+  float *cache;        // [slot_cap][12][896]
+  int2 *slot_owner;    // [slot_cap]: (chain, k) of every slot handed out
+  int *slot_next;      // slots handed out so far (may run past slot_cap: the excess does not exist)
+  int slot_cap;
+  int pass;
 };
+constexpr int kCacheStripLags = 64 * kStripRegs;   // 896 floats per (slot, strip)
+constexpr int kCacheMinSearches = 6;               // fewer searches ahead than this: not worth a pass of its own
+constexpr int kCacheMaxPerChain = 256;
+__host__ __device__ constexpr size_t cache_slot_floats() { return (size_t)kStrips * kCacheStripLags; }
 
 struct SearchResult {
   int peak_pos;
@@ -76,12 +88,45 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
 // srslte_pss_find_pss on the window whose strip samples are in x (strip_load).  resolve = false: lag metric and
 // exponential average only (a window the scan has already turned into a record).  Contains workgroup
 // barriers; `buf` alternates between calls.
-__device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane,
-                                                     ema_t &ema, int &buf, bool resolve)
+// cached: the window's lag metric as lt_metric_kernel left it (12 x 896 floats) -- the transforms are skipped, the
+// average and everything after it run as ever (x is not looked at then).
+// The warm-up loads of a cached search (below) go into ONE register that nobody reads; the compiler must know it to be
+// taken until they have landed, so it stays an operand from the loads to the wait that closes them -- at the start of
+// the next search, a whole window later, when they have long landed.
+struct WarmUp {
+  float sink = 0.f;
+  bool on = false;
+};
+__device__ __forceinline__ void warm_up_landed(WarmUp &wu)
+{
+  if (wu.on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wu.sink)::"memory");
+  wu.on = false;
+}
+__device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane, ema_t &ema, int &buf,
+                                                     bool resolve, WarmUp &wu, const float *cached = nullptr,
+                                                     const float *cache_end = nullptr)
 {
   fft::c32 *e = L.E + w * fft::kScratchW;
-  strip_fft<false>(lane, x, L.TW1, L.TW2, e);
-  strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
+  warm_up_landed(wu);
+  if (cached) {
+    float met[kStripRegs];
+    const float *m = cached + (size_t)w * kCacheStripLags + lane;
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) met[r] = m[64 * r];
+    // The slot after this one is what the chain will want next if it stays on its grid: its lines are pulled into
+    // this XCD's L2 now, so that the search after this one finds them there instead of in HBM (WarmUp above).
+    if (cached + cache_slot_floats() < cache_end) {
+      const float *n = m + cache_slot_floats();
+      wu.on = true;
+#pragma unroll
+      for (int r = 0; r < kStripRegs; ++r)
+        asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(wu.sink) : "v"(n), "n"(256 * r) : "memory");
+    }
+    strip_ema_apply(w, lane, met, ema);
+  } else {
+    strip_fft<false>(lane, x, L.TW1, L.TW2, e);
+    strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
+  }
   SearchResult out;
   out.peak_pos = 0;
   out.peak_value = 0.f;
@@ -93,7 +138,7 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[
   buf ^= 1;
   if (lane == 0) parts[w] = p;
   __syncthreads();
-  const WindowResult r = resolve_window(parts);
+  const WindowResult r = resolve_window_unrolled(parts); // (the reads of a loop in flight together, not in turn)
   out.peak_pos = __builtin_amdgcn_readfirstlane(r.peak_pos);
   out.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.peak_value)));
   out.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.psr)));
@@ -180,6 +225,50 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
   // average is still described through windows of this chunk (pre_n): those samples will be gone by the next one
   if (!(can_call(pos) && nrec < a.rec_cap) && st->pre_n == 0) return;
 
+  // ---- pass 0 of two: a chain with many searches ahead of it -- all on the grid it stands on, unless a hit moves it --
+  // asks for their lag metric (lt_metric_kernel forms them for all such chains at once, chip-wide) and leaves
+  // everything to pass 1.  An idle or acquiring chain searches every window from pos on; a tracked one every
+  // (track_every + 1)-th from its next search on.  (Windows its average still has to be run through -- pre_n -- are
+  // found in the cache if they lie on the same grid, and go through the transforms if not.)
+  if (a.cache && a.pass == 0 && can_call(pos) && nrec < a.rec_cap) {
+    const int stride = st->is_tracking ? a.track_every + 1 : 1;
+    const int64_t first = pos + (st->is_tracking ? (int64_t)st->timer * kHalfFrame : 0);
+    const int64_t last_start = a.flush ? t1 - kHalfFrame : t1 - kCallReach; // last position a call may start at
+    int64_t ahead = first <= last_start ? (last_start - first) / ((int64_t)stride * kHalfFrame) + 1 : 0;
+    if (ahead > kCacheMaxPerChain) ahead = kCacheMaxPerChain;
+    if (ahead >= kCacheMinSearches) {
+      __shared__ int s_base;
+      if (tid == 0) s_base = atomicAdd(a.slot_next, (int)ahead);
+      __syncthreads();
+      const int base = s_base;
+      int got = a.slot_cap - base < (int)ahead ? a.slot_cap - base : (int)ahead;
+      if (got >= kCacheMinSearches) {
+        for (int i = tid; i < got; i += NT) a.slot_owner[base + i] = make_int2(chain, i);
+        if (tid == 0) {
+          atomicAdd(a.slot_next + 3, 1); // diagnostics
+          st->cache_pos = first;
+          st->cache_base = base;
+          st->cache_n = got;
+          st->cache_stride = stride;
+        }
+        return; // (untouched: pass 1 takes the chain from here)
+      }
+    }
+  }
+  const float *cache0 = nullptr;
+  int64_t cache_pos = 0, cache_step = 1;
+  int cache_n = 0;
+  if (a.cache && a.pass == 1 && st->cache_n > 0) {
+    cache0 = a.cache + (size_t)st->cache_base * cache_slot_floats();
+    cache_pos = st->cache_pos;
+    cache_step = (int64_t)st->cache_stride * kHalfFrame;
+    cache_n = st->cache_n;
+  }
+  const float *cache_end = cache0 ? cache0 + (size_t)cache_n * cache_slot_floats() : nullptr;
+  WarmUp warm;
+  int64_t cache_next_pos = cache_pos; // the window of slot cache_next_k: where a chain that stays on its grid searches next
+  int cache_next_k = 0;
+
   // ---- load state.  The average is avg[ema_sel] (or all zeros after srslte_pss_reset) run through the pre_n
   // windows of a scan round the chain did not follow to its end: brought up to date before the first search,
   // by the same search call as every other window.
@@ -265,8 +354,26 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       int ln = lane;
       asm volatile("" : "+v"(ln));
       fft::c32 x[16];
-      strip_load(cap, wpos, w, ln, x);
-      const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo);
+      // the window's lag metric may be in the cache (pass 1, a window on the grid the chain stood on in pass 0)
+      const float *cached = nullptr;
+      if (cache_n > 0 && wpos >= cache_pos) {
+        int64_t kq;
+        if (wpos == cache_next_pos) { // (the usual case: no division)
+          kq = cache_next_k;
+        } else {
+          const int64_t d = wpos - cache_pos;
+          kq = d / cache_step;
+          if (kq * cache_step != d) kq = -1;
+        }
+        if (kq >= 0 && kq < cache_n) {
+          cached = cache0 + (size_t)kq * cache_slot_floats();
+          cache_next_k = (int)kq + 1;
+          cache_next_pos = wpos + cache_step;
+        }
+      }
+      if (!cached) strip_load(cap, wpos, w, ln, x);
+      if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached ? 5 : 6) : (cached ? 1 : 2)), 1); // diagnostics
+      const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end);
       searched = true;
       if (redo) {
         redo_k++;
@@ -312,6 +419,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       const int frame_start = peak_pos - kSlotLen;
       peak_pos = kSlotLen;
       const int64_t hf0 = pos + frame_start;
+      if (cache_n > 0 && frame_start != 0 && tid == 0) atomicAdd(a.slot_next + 4, 1); // diagnostics
       if (hf0 + kHalfFrame > t1) break; // (flush only) quirk q1 normalised: never read past the capture
       next_pos = hf0 + kHalfFrame;
       out_pos = hf0;
@@ -336,6 +444,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
     pos = next_pos;
   }
 
+  warm_up_landed(warm);
   // ---- store state
   __syncthreads();
   if (searched && redo_k >= redo_end) strip_ema_store(avg, w, lane, ema); // (else: the average is described as before)
@@ -364,6 +473,11 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
   __threadfence_block();
   __syncthreads();
   const int chain = blockIdx.x, lane = threadIdx.x & 63;
+  // (with two passes: a chain whose records pass 0 left final is listed then; one that waits for the cache, in pass 1)
+  ChainState *st = a.state + chain;
+  if (st->listed || (a.cache && a.pass == 0 && st->cache_n > 0)) return;
+  __syncthreads();
+  if (threadIdx.x == 0) st->listed = 1;
   const int count = a.rec_count[chain];
   const lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
   for (int i = threadIdx.x; i < ((count + 63) & ~63); i += kChainThreads) {
@@ -374,6 +488,75 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     if (lane == 0) base = atomicAdd(a.list_count, __builtin_popcountll(m));
     base = __builtin_amdgcn_readfirstlane(base);
     if (ran) a.list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(chain, i);
+  }
+}
+
+// ---------------------------------------------------------------- window cache: the lag metric in bulk
+// The lag metric of a window does not depend on the chain's state, only the average that follows it does: for the
+// chains pass 0 of the per-chain kernel has put on the list, the metric of every coming window is formed here, one
+// wave per (window, strip), with nothing sequential about it -- 16 waves per CU, every CU of the chip -- and the
+// per-chain kernel's pass 1 is left with the average, the peak search and general_work.  Same instruction sequence
+// as the search itself (strip_load, strip_fft, strip_root_lags, strip_metric): same bits.
+struct MetricArgs {
+  const v2f *iq;
+  int64_t ch_stride;
+  const v2f *hist;
+  int64_t hist_stride;
+  int64_t t0, n, hist_len;
+  const ChainState *state;
+  const int2 *slot_owner;
+  const int *slot_next;
+  int slot_cap;
+  float *cache;
+  const DeviceTables *tab;
+};
+constexpr int kMetricWaves = 8;
+__global__ __launch_bounds__(64 * kMetricWaves) void lt_metric_kernel(MetricArgs a)
+{
+  __shared__ __attribute__((aligned(16))) v2f E[kMetricWaves * fft::kScratchW];
+  __shared__ __attribute__((aligned(16))) fft::c32 TW1[fft::kTw1Len];
+  __shared__ __attribute__((aligned(16))) fft::c32 TW2[fft::kTw2Len];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n_slots = *a.slot_next;
+  if (n_slots > a.slot_cap) n_slots = a.slot_cap;
+  const int n_items = n_slots * kStrips;
+  if ((int)blockIdx.x * kMetricWaves >= n_items) return;
+  for (int i = tid; i < fft::kTw1Len; i += 64 * kMetricWaves) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
+  if (tid < fft::kTw2Len) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
+  __syncthreads();
+  fft::c32 *e = E + w * fft::kScratchW;
+  for (int item = blockIdx.x * kMetricWaves + w; item < n_items; item += gridDim.x * kMetricWaves) {
+    const int slot = item / kStrips, strip = item - slot * kStrips;
+    const int2 own = a.slot_owner[slot];
+    const int chain = __builtin_amdgcn_readfirstlane(own.x), k = __builtin_amdgcn_readfirstlane(own.y);
+    const ChainState *st = a.state + chain;
+    const int64_t wpos = uniform_i64(st->cache_pos + (int64_t)k * st->cache_stride * kHalfFrame);
+    Capture cap;
+    cap.iq = a.iq + (int64_t)(chain / 3) * a.ch_stride;
+    cap.hist = a.hist ? a.hist + (int64_t)(chain / 3) * a.hist_stride : nullptr;
+    cap.t0 = a.t0;
+    cap.n = a.n;
+    cap.hist_len = a.hist ? a.hist_len : 0;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    fft::c32 x[16];
+    strip_load(cap, wpos, strip, ln, x);
+    strip_fft<false>(ln, x, TW1, TW2, e);
+    v2f spec[16];
+#pragma unroll
+    for (int R = 0; R < 16; ++R) {
+      const cf32 hh = a.tab->pss_spec[chain % 3][ln + 64 * R];
+      spec[R] = v2f{hh.re, hh.im};
+    }
+    fft::Twiddles tw;
+    fft::stageA_twiddles(ln, TW1, tw);
+    strip_root_lags(ln, x, spec, tw, TW2, e);
+    float met[kStripRegs];
+    strip_metric(x, met);
+    float *out = a.cache + (size_t)slot * cache_slot_floats() + (size_t)strip * kCacheStripLags + ln;
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) out[64 * r] = met[r];
   }
 }
 
@@ -398,7 +581,8 @@ __global__ __launch_bounds__(kChainThreads) void lt_find_kernel(const v2f *__res
   int buf = 0;
   fft::c32 x[16];
   strip_load(cap, 0, w, lane, x);
-  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true);
+  WarmUp none;
+  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true, none);
   strip_ema_store(avg, w, lane, ema);
   if (tid == 0) {
     res->peak_pos = r.peak_pos;

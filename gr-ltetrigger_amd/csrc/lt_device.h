@@ -59,7 +59,14 @@ struct ChainState {
   int32_t run_done;     // the chain has stopped for this run (nothing more fits into the chunk, or records are full)
   int32_t need_chain;   // the per-chain kernel takes the chain from here (a window the strips could not resolve)
   int32_t scan_job;     // this round: its job, -1 = none
-  int32_t scan_pad;
+  int32_t listed;       // this run: the chain's tracked half-frames are on the per-record work list
+  // ---- this run's window cache (lt_metric_kernel): the lag metric of the windows cache_pos + k * cache_stride * 9600,
+  // k < cache_n, sits in cache slots cache_base + k (12 strips x 896 lags each)
+  int64_t cache_pos;
+  int32_t cache_base;
+  int32_t cache_n;
+  int32_t cache_stride;
+  int32_t cache_pad;
   float psr_data[kMovingAvgSz];
   float cfo_data[kMovingAvgSz];
   float avg[3][kConvLen]; // srslte_pss_t::conv_output_avg (lags >= 9726 stay 0), natural lag order

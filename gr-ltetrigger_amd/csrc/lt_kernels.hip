@@ -629,7 +629,11 @@ int scan_job_bytes() { return (int)sizeof(ScanJob); }
 int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips * kScanMaxRound); }
 int scan_max_round() { return kScanMaxRound; }
 int scan_max_rounds() { return kMaxRounds; }
-int scan_counter_ints() { return 2 * (kMaxRounds + 1) + 2; } // job counters of every round + the per-record work list's
+int scan_counter_ints() { return 2 * (kMaxRounds + 1) + 3 + 6; } // ... + six diagnostic counts behind it (lt_batch_cache_stats)
+int cache_counter_index() { return 2 * (kMaxRounds + 1) + 2; }
+int scan_counter_ints_legacy() { return 2 * (kMaxRounds + 1) + 3; } // job counters of every round + the per-record work lists' + the window cache's
+int cache_slot_bytes() { return (int)(cache_slot_floats() * sizeof(float)); }
+int cache_max_per_chain() { return kCacheMaxPerChain; }
 int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + 2 * sizeof(int2)); } // CP metrics + one work-list entry for each of the two list slots
 
 // The work lists sit behind the CP metrics in the per-record scratch buffer, one per list slot (their counters
@@ -716,7 +720,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     p.n_jobs = R.n_jobs;
     p.jobs_cap = s.jobs_cap = n_chains;
     p.n_counters = scan_counter_ints();
-    p.keep_counter = 2 * (kMaxRounds + 1) + (R.list_slot ? 0 : 1); // the other run's work-list counter
+    p.keep_counter = 2 * (kMaxRounds + 1) + (R.list_slot ? 0 : 1); // the other run's work-list counter (the cache's, behind them, is this run's)
     p.rebase = R.rebase;
     hipLaunchKernelGGL(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
@@ -791,7 +795,24 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.track_every = R.track_every;
     c.list = work_list(R, n_chains);
     c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
+    c.cache = reinterpret_cast<float *>(R.cache);
+    c.slot_owner = reinterpret_cast<int2 *>(R.slot_owner);
+    c.slot_next = R.n_jobs + 2 * (kMaxRounds + 1) + 2; // (cleared with the run's other counters by its first launch)
+    c.slot_cap = R.slot_cap;
+    c.pass = 0;
+    if (!(c.cache && c.slot_owner && c.slot_cap > 0)) c.cache = nullptr;
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+    if (c.cache) {
+      // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
+      MetricArgs m;
+      m.iq = iq; m.ch_stride = R.ch_stride; m.hist = hist; m.hist_stride = R.hist_stride; m.t0 = R.t0; m.n = R.n;
+      m.hist_len = R.hist_len; m.state = state; m.slot_owner = c.slot_owner; m.slot_next = c.slot_next; m.slot_cap = c.slot_cap;
+      m.cache = c.cache; m.tab = R.tab;
+      const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
+      hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);
+      c.pass = 1;
+      hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+    }
   }
   if (R.ev_chain_done) (void)hipEventRecord(R.ev_chain_done, stream);
   // ---- per-record kernels: CP length and SSS of the tracked half-frames.  They feed nothing but the records, so they

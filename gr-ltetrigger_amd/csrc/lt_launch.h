@@ -42,11 +42,15 @@ struct RunLaunch {
   int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
   int scan_groups = 0;        // strips per scan workgroup: 1, 2 or 3; 0 = chosen from n_channels and n_cus
   int n_cus = 0;              // compute units of the device (0: 256)
-  int extra_rounds = 1;       // rounds beyond what an idle chain needs (two empty launches, 9 us, when nothing is left to do)
+  int extra_rounds = 0;       // rounds beyond what an idle chain needs (what the rounds leave over goes through the window cache)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the two work lists
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr; // (required when the per-record kernels go to a stream of their own)
   int rebase = 0;             // the run is a capture of its own: the chains' positions restart at 0
+  void *cache = nullptr;      // device, slot_cap x cache_slot_bytes(): the window cache (lag metrics formed in bulk for the chains the
+                              // scan rounds leave to the per-chain kernel); null: no cache, the per-chain kernel runs once
+  void *slot_owner = nullptr; // device, slot_cap x int2
+  int slot_cap = 0;
   int records_delay_us = 0;   // diagnostics (lt_batch_debug_hold_records): the per-record kernels start this much later
   int list_slot = 0;          // which of the two work lists (and of their counters behind the job counters) this run uses (0 / 1)
 };
@@ -64,6 +68,10 @@ int scan_max_round();
 int scan_max_rounds();
 int scan_counter_ints();
 int per_record_scratch_bytes();
+int cache_slot_bytes();
+int cache_counter_index(); // d_njobs[this] = slots asked for; [+1] searches served from the cache, [+2] searches through the
+                           // transforms in pass 1, [+3] chains that waited for the cache, [+4] hits that moved a waiting chain off its grid
+int cache_max_per_chain();
 size_t chain_state_bytes();
 size_t chain_state_avg_offset();
 

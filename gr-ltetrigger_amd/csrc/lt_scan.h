@@ -245,6 +245,51 @@ template <typename Ptr> __device__ __forceinline__ WindowResult resolve_window(P
   return w;
 }
 
+// The same with both loops unrolled, for partials in LDS (the per-chain kernel, wave-uniform): the maxima are read
+// together, then the fields of the second loop -- 16-byte reads of twelve structures at once would cost 48 registers
+// the per-chain kernel does not have.
+template <typename Ptr> __device__ __forceinline__ WindowResult resolve_window_unrolled(Ptr parts)
+{
+  float m1[kStrips];
+#pragma unroll
+  for (int s = 0; s < kStrips; ++s) m1[s] = parts[s].m1;
+  int best = 0;
+  float bm = m1[0];
+#pragma unroll
+  for (int s = 1; s < kStrips; ++s)
+    if (m1[s] > bm) {
+      bm = m1[s];
+      best = s;
+    }
+  WindowResult w;
+  const uint32_t bflags = parts[best].flags;
+  w.exact = !(bflags & kPartWide);
+  w.peak_value = bm;
+  w.peak_pos = (bm > -FLT_MAX) ? parts[best].p1 : 0;
+  const int lb = parts[best].lb, ub = parts[best].ub;
+  float out = parts[best].s;
+  int p1[kStrips];
+  float sv[kStrips];
+#pragma unroll
+  for (int s = 0; s < kStrips; ++s) {
+    p1[s] = parts[s].p1;
+    sv[s] = parts[s].s;
+  }
+#pragma unroll
+  for (int s = 0; s < kStrips; ++s) {
+    if (s == best) continue;
+    const bool inside = p1[s] >= lb && p1[s] < ub;
+    if (inside && (parts[s].flags & kPartWide)) w.exact = false;
+    const float v = inside ? sv[s] : m1[s];
+    if (v > out) out = v;
+  }
+  const float sl = (w.peak_pos <= 2) ? parts[0].a0 : out;
+  const float sr = (ub >= kNLags) ? 0.f : out;
+  const float side = sl > sr ? sl : sr;
+  w.psr = w.peak_value / side;
+  return w;
+}
+
 // The same for partials in global memory, one lane per window (the resolver kernel): the twelve strips' leading
 // halves (m1, p1, s, lb) are fetched together -- twelve loads in flight instead of twenty-four round trips, one per
 // step of the two loops above -- and what else a window needs (the peak strip's ub and flags; rarely a neighbour's
@@ -379,9 +424,21 @@ template <bool kInv> __device__ __forceinline__ void strip_fft(int lane, fft::c3
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// |.|^2 of the strip's lags and the exponential average with its three roundings (srsLTE's three vector passes,
-// oracle/lte_oracle.c:289-293).  Lags outside [0, 9726) stay 0.
-__device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32 (&v)[16], ema_t &ema)
+// |.|^2 of the strip's lags: met[r] = metric of lag c0 + lane + 64 r
+__device__ __forceinline__ void strip_metric(const fft::c32 (&v)[16], float (&met)[kStripRegs])
+{
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) {
+    const fft::c32 y = v[r + 2];
+    const fft::c32 sq = y * y;
+    float m; // (as assembly: left to itself the compiler shuffles two lags' squares into pairs to add them packed)
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(sq.x), "v"(sq.y));
+    met[r] = m;
+  }
+}
+// ... and the exponential average with its three roundings (srsLTE's three vector passes, oracle/lte_oracle.c:289-293).
+// Lags outside [0, 9726) stay 0.
+__device__ __forceinline__ void strip_ema_apply(int s, int lane, const float (&met)[kStripRegs], ema_t &ema)
 {
   const bool valid0 = !(s == 0 && lane < kStripHalo);
   const int end13 = kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13; // strip 11: lanes below hold lags < 9726
@@ -390,29 +447,28 @@ __device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32
   typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int r = 0; r < kStripRegs; r += 2) {
-    f2 met;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const fft::c32 y = v[r + h + 2];
-      const fft::c32 sq = y * y;
-      float m; // (as assembly: left to itself the compiler shuffles two lags' squares into pairs to add them packed)
-      asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(sq.x), "v"(sq.y));
-      met[h] = m;
-    }
+    const f2 m2 = {met[r], met[r + 1]};
     const f2 old = {ema[r], ema[r + 1]};
-    const f2 ne = met * 0.2f + old * (1.0f - 0.2f); // (no contraction: the build has -ffp-contract=off)
+    const f2 ne = m2 * 0.2f + old * (1.0f - 0.2f); // (no contraction: the build has -ffp-contract=off)
     ema[r] = ne.x;
     ema[r + 1] = ne.y;
   }
   ema[0] = valid0 ? ema[0] : 0.f;
   ema[kStripRegs - 1] = valid13 ? ema[kStripRegs - 1] : 0.f;
 }
+__device__ __forceinline__ void strip_ema_update(int s, int lane, const fft::c32 (&v)[16], ema_t &ema)
+{
+  float met[kStripRegs];
+  strip_metric(v, met);
+  strip_ema_apply(s, lane, met, ema);
+}
 
 // One window of one root of one strip: spectrum of the block (X) times the filter spectrum, back to the lag
 // domain, then the average.  spec = the filter spectrum's bins lane + 64 R, tw = the inverse transform's
 // first-stage twiddles: both read by the caller ahead of time.
-__device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
-                                                  const fft::c32 *tw2, fft::c32 *e, ema_t &ema)
+// (the same up to the lags: v = the matched filter's output, element lane + 64 R in v[R])
+__device__ __forceinline__ void strip_root_lags(int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
+                                                const fft::c32 *tw2, fft::c32 *e)
 {
 #pragma unroll
   for (int R = 0; R < 16; R += 2) fft::cmulw2<false>(v[R], spec[R], v[R + 1], spec[R + 1]);
@@ -422,6 +478,11 @@ __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)
   __builtin_amdgcn_sched_barrier(0);
   fft::fft1024w_stageC<true>(lane, v, e);
   __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f (&spec)[16], const fft::Twiddles &tw,
+                                                  const fft::c32 *tw2, fft::c32 *e, ema_t &ema)
+{
+  strip_root_lags(lane, v, spec, tw, tw2, e);
   strip_ema_update(s, lane, v, ema);
 }
 __device__ __forceinline__ void strip_root_update(int s, int lane, fft::c32 (&v)[16], const v2f *spec_tab,

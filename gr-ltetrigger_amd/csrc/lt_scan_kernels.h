@@ -374,6 +374,8 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
       a.rec_count[c * 3 + r] = 0;
       st->run_done = 0;
       st->need_chain = 0;
+      st->listed = 0;
+      st->cache_n = 0;
     }
     st->scan_job = -1;
     n[r] = 0;

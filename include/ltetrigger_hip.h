@@ -173,6 +173,17 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
+/* Window cache (default 1).  What the scan rounds leave over -- chains that keep firing and losing a weak cell,
+ * every chain in mode 0 -- the per-chain kernel takes in two passes: the first lists the windows every such chain has
+ * ahead of it on its present timing, lt_metric_kernel forms their lag metrics for all chains at once, chip-wide, and
+ * the second pass runs general_work on them (a window off the list goes through the transforms there and then).
+ * 0 = one pass, every search through the transforms.  Same records either way. */
+int lt_batch_set_window_cache(lt_batch *b, int on);
+/* Diagnostics of the last run: stats[0] = windows asked for, [1] = searches of the second pass served from the cache,
+ * [2] = searches of the second pass that went through the transforms, [3] = chains that waited for the cache,
+ * [4] = hits that moved such a chain off the timing its windows were listed on, [5] / [6] = windows a chain's average
+ * had to be run through again (left over from a scan round), from the cache / through the transforms. */
+int lt_batch_cache_stats(lt_batch *b, int64_t stats[7]);
 /* Overlap (default 0): with 1, the per-record kernels of an lt_batch_run on a device buffer (CFO, CP, SSS: they feed
  * nothing but the records) are enqueued on a stream of the batch's own and run beside the scan rounds of the next
  * lt_batch_run; two sets of records take turns.  The run's stream then does NOT wait for them: the records are

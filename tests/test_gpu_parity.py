@@ -528,6 +528,33 @@ def test_overlap_gives_the_same_records(lt, oracle, frames_192):
 
 
 @pytest.mark.parametrize("mode", [1, 0])
+def test_window_cache_gives_the_same_records(lt, oracle, frames_192, mode):
+    """lt_batch_set_window_cache: the per-chain kernel in two passes with the lag metrics of its windows formed in bulk
+    (lt_metric_kernel) against the one-pass kernel that runs every search through the transforms -- weak cells that keep
+    firing and losing (chains the scan rounds leave over, hits that move a chain off the windows it listed), and
+    every chain in mode 0: bit for bit the same records; the cache is actually used; the first against the oracle."""
+    base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
+    iq, _ = siggen.scan_channels(base, 6, 90 * 9600 + 41, snr_db=1.0, cfo=True, seed0=270)
+    out = {}
+    for cache in (1, 0):
+        b = lt.Batch(6, iq.shape[1])
+        b.set_mode(mode)
+        b.set_window_cache(cache)
+        b.run_host(iq)
+        out[cache] = [r.copy() for r in b.collect()]
+        stats = b.cache_stats()
+        if cache:
+            assert stats[3] > 0 and stats[1] > 50, f"the scene must send chains through the cache: {stats}"
+        else:
+            assert stats[0] == 0 and stats[1] == 0
+    for c in range(18):
+        assert out[1][c].tobytes() == out[0][c].tobytes(), f"chain {c}"
+    want = oracle.batch_run(iq, nthreads=8)
+    for c in range(18):
+        assert_records_match(out[1][c], want[c], f"chain {c}")
+
+
+@pytest.mark.parametrize("mode", [1, 0])
 def test_overlap_with_the_next_run_in_flight(lt, oracle, frames_192, mode):
     """The window the overlap mode opens, held open: every run's per-record kernels are kept back (3 ms, far longer than
     a run of these short captures) so that the next run's launches -- its per-chain kernel fills the next work list --
