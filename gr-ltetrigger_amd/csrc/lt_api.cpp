@@ -559,8 +559,18 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
     // window cache: room for every chain's windows of a run, up to 16384 of them (43 KB each)
     const int64_t per_chain = std::min<int64_t>(max_samples / LT_HALF_FRAME_LEN + 2, lt::cache_max_per_chain());
     b->cache_slots = (int)std::min<int64_t>((int64_t)nchains * per_chain, 16384);
-    if (e == hipSuccess) e = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
-    if (e == hipSuccess) e = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
+    if (e == hipSuccess) {
+      // (an accelerator, not a necessity: without the memory for it the per-chain kernel runs in one pass)
+      hipError_t ce = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
+      if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
+      if (ce != hipSuccess) {
+        (void)hipGetLastError();
+        if (b->d_cache) (void)hipFree(b->d_cache);
+        b->d_cache = nullptr;
+        b->d_slot_owner = nullptr;
+        b->cache_slots = 0;
+      }
+    }
   }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);

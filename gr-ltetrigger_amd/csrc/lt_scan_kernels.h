@@ -361,6 +361,16 @@ struct PlanArgs {
   int n_counters, keep_counter, rebase;
 };
 
+// floor(d / step) for 0 <= d < 2^52, step > 0: through a double-precision quotient and a correction by one (a 64-bit
+// integer division is a hundred dependent instructions, and the plan runs on one thread per channel)
+__device__ __forceinline__ int64_t div_floor_pos(int64_t d, int64_t step)
+{
+  int64_t q = (int64_t)((double)d / (double)step);
+  if (q * step > d) --q;
+  else if ((q + 1) * step <= d) ++q;
+  return q;
+}
+
 // the job of channel c for the next round
 __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
 {
@@ -368,7 +378,8 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
   int64_t first[3], pos_c[3];
   bool plain[3]; // the average is a stored state as it stands (avg[ema_sel], or the zeros a stream starts from), and the windows end with the round
   const int64_t limit = a.t1 - (a.flush ? kHalfFrame : a.call_reach); // last position a call may start at
-  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { // (unrolled: the three chains' state comes in together, not chain after chain)
     ChainState *st = a.state + c * 3 + r;
     if (a.first_round) {
       a.rec_count[c * 3 + r] = 0;
@@ -388,7 +399,7 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     plain[r] = st->pre_n == 0 && (st->ema_zero == 0 || fresh[r]);
     if (!a.enable || st->run_done || st->need_chain || st->tracking_lost) continue;
     if (first[r] > limit) continue;
-    int64_t m = (limit - first[r]) / ((int64_t)stride[r] * kHalfFrame) + 1;
+    int64_t m = div_floor_pos(limit - first[r], (int64_t)stride[r] * kHalfFrame) + 1;
     const int64_t room = (a.rec_cap - a.rec_count[c * 3 + r]) / stride[r]; // a window makes at most `stride` records
     if (m > room) m = room;
     if (m > a.round_windows) m = a.round_windows;
@@ -415,7 +426,7 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
       const int sc = a.track_every + 1;
       const int64_t pc = first[r] + (int64_t)(hits - 1) * kHalfFrame + (int64_t)sc * kHalfFrame;
       if (pc <= limit) {
-        int64_t mc = (limit - pc) / ((int64_t)sc * kHalfFrame) + 1;
+        int64_t mc = div_floor_pos(limit - pc, (int64_t)sc * kHalfFrame) + 1;
         const int64_t room_c = (a.rec_cap - a.rec_count[c * 3 + r] - hits - a.track_every) / sc;
         if (mc > room_c) mc = room_c;
         if (mc > a.round_windows - n[r]) mc = a.round_windows - n[r];
