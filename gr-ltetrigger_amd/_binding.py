@@ -344,9 +344,10 @@ class Batch:
         """Per-record kernels of a device run beside the next run's scan rounds (lt_batch_set_overlap)."""
         _check(lib().lt_batch_set_overlap(self._h, 1 if on else 0), "lt_batch_set_overlap")
 
-    def set_window_cache(self, on):
-        """Lag metrics of the per-chain kernel's windows formed in bulk (lt_batch_set_window_cache)."""
-        _check(lib().lt_batch_set_window_cache(self._h, 1 if on else 0), "lt_batch_set_window_cache")
+    def set_window_cache(self, level):
+        """Lag metrics formed in bulk: 0 = never, 1 = for the per-chain kernel, 2 = also for the scan rounds of small
+        batches (lt_batch_set_window_cache)."""
+        _check(lib().lt_batch_set_window_cache(self._h, int(level)), "lt_batch_set_window_cache")
 
     def cache_stats(self):
         """(windows asked for, cached searches, uncached searches of pass 1, chains that waited, hits that moved one off its grid)."""

@@ -152,8 +152,9 @@ struct lt_batch {
   void *d_parts = nullptr;   // grid scan: the partial results of a round, per chain
   void *d_cache = nullptr;   // window cache: cache_slots x cache_slot_bytes()
   void *d_slot_owner = nullptr;
+  void *d_slot_pos = nullptr;
   int cache_slots = 0;
-  int use_cache = 1;         // lt_batch_set_window_cache
+  int use_cache = 2;         // lt_batch_set_window_cache
   void *d_cp = nullptr;      // per-record scratch (CP metrics, work list), [n_channels*3][rec_cap] x per_record_scratch_bytes()
   lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
   int hist_sel = 0;
@@ -557,17 +558,23 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)lt::per_record_scratch_bytes() * nchains * (size_t)b->rec_cap);
   {
     // window cache: room for every chain's windows of a run, up to 16384 of them (43 KB each)
-    const int64_t per_chain = std::min<int64_t>(max_samples / LT_HALF_FRAME_LEN + 2, lt::cache_max_per_chain());
+    // (a small batch scans from the cache: its rounds list windows ahead of chains that may leave them early, up to
+    // three times what a chain ends up searching)
+    const int64_t windows = max_samples / LT_HALF_FRAME_LEN + 2;
+    const int64_t per_chain = n_channels <= 4 ? 3 * windows + 16 : std::min<int64_t>(windows, lt::cache_max_per_chain());
     b->cache_slots = (int)std::min<int64_t>((int64_t)nchains * per_chain, 16384);
     if (e == hipSuccess) {
       // (an accelerator, not a necessity: without the memory for it the per-chain kernel runs in one pass)
       hipError_t ce = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
       if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
+      if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_pos, (size_t)b->cache_slots * sizeof(int64_t));
       if (ce != hipSuccess) {
         (void)hipGetLastError();
         if (b->d_cache) (void)hipFree(b->d_cache);
+        if (b->d_slot_owner) (void)hipFree(b->d_slot_owner);
         b->d_cache = nullptr;
         b->d_slot_owner = nullptr;
+        b->d_slot_pos = nullptr;
         b->cache_slots = 0;
       }
     }
@@ -596,7 +603,7 @@ void lt_batch_free(lt_batch *b)
   (void)hipSetDevice(b->device);
   if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
   if (b->side) (void)hipStreamSynchronize(b->side);
-  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1], b->d_cache, b->d_slot_owner,
+  void *bufs[] = {b->d_iq, b->d_state, b->d_recs, b->d_count, b->d_hf, b->d_jobs, b->d_njobs, b->d_parts, b->d_cp, b->d_hist[0], b->d_hist[1], b->d_cache, b->d_slot_owner, b->d_slot_pos,
                   b->d_recs_b, b->d_count_b};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
@@ -732,7 +739,9 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.n_cus = b->n_cus;
   R.cp_scratch = b->d_cp;
   R.cache = b->use_cache ? b->d_cache : nullptr;
+  R.cache_level = b->use_cache;
   R.slot_owner = b->d_slot_owner;
+  R.slot_pos = b->d_slot_pos;
   R.slot_cap = b->cache_slots;
   R.records_delay_us = b->records_delay_us;
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
@@ -953,7 +962,7 @@ int lt_batch_cache_stats(lt_batch *b, int64_t stats[7])
 
 int lt_batch_set_window_cache(lt_batch *b, int on)
 {
-  if (!b || (on != 0 && on != 1)) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0 or 1");
+  if (!b || on < 0 || on > 2) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0, 1 or 2");
   b->use_cache = on;
   return LT_OK;
 }

@@ -49,7 +49,9 @@ struct ChainArgs {
   // taking the lag metric of a window from the cache where it is there.  cache == null: one pass, no cache.
   float *cache;        // [slot_cap][12][896]
   int2 *slot_owner;    // [slot_cap]: (chain, k) of every slot handed out
-  int *slot_next;      // slots handed out so far (may run past slot_cap: the excess does not exist)
+  int64_t *slot_pos;   // [slot_cap]: the window's position
+  int *slot_next;      // slots handed out so far in this run (may run past slot_cap: the excess does not exist)
+  int *launch_slots;   // ... those of them that pass 0 hands out (lt_metric_kernel's share of the work)
   int slot_cap;
   int pass;
 };
@@ -243,8 +245,12 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       const int base = s_base;
       int got = a.slot_cap - base < (int)ahead ? a.slot_cap - base : (int)ahead;
       if (got >= kCacheMinSearches) {
-        for (int i = tid; i < got; i += NT) a.slot_owner[base + i] = make_int2(chain, i);
+        for (int i = tid; i < got; i += NT) {
+          a.slot_owner[base + i] = make_int2(chain, i);
+          a.slot_pos[base + i] = first + (int64_t)i * stride * kHalfFrame;
+        }
         if (tid == 0) {
+          atomicAdd(a.launch_slots, got);
           atomicAdd(a.slot_next + 3, 1); // diagnostics
           st->cache_pos = first;
           st->cache_base = base;
@@ -503,9 +509,10 @@ struct MetricArgs {
   const v2f *hist;
   int64_t hist_stride;
   int64_t t0, n, hist_len;
-  const ChainState *state;
   const int2 *slot_owner;
-  const int *slot_next;
+  const int64_t *slot_pos;
+  const int *launch_slots; // [n_before + 1]: slots handed out for the launches before this one, then for this one
+  int n_before;
   int slot_cap;
   float *cache;
   const DeviceTables *tab;
@@ -518,8 +525,11 @@ __global__ __launch_bounds__(64 * kMetricWaves) void lt_metric_kernel(MetricArgs
   __shared__ __attribute__((aligned(16))) fft::c32 TW2[fft::kTw2Len];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int n_slots = *a.slot_next;
-  if (n_slots > a.slot_cap) n_slots = a.slot_cap;
+  // this launch's slots: those handed out since the launch before (the slots in use are contiguous from 0)
+  int slot0 = 0;
+  for (int i = 0; i < a.n_before; ++i) slot0 += a.launch_slots[i];
+  int n_slots = a.launch_slots[a.n_before];
+  if (slot0 + n_slots > a.slot_cap) n_slots = a.slot_cap - slot0;
   const int n_items = n_slots * kStrips;
   if ((int)blockIdx.x * kMetricWaves >= n_items) return;
   for (int i = tid; i < fft::kTw1Len; i += 64 * kMetricWaves) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
@@ -527,11 +537,9 @@ __global__ __launch_bounds__(64 * kMetricWaves) void lt_metric_kernel(MetricArgs
   __syncthreads();
   fft::c32 *e = E + w * fft::kScratchW;
   for (int item = blockIdx.x * kMetricWaves + w; item < n_items; item += gridDim.x * kMetricWaves) {
-    const int slot = item / kStrips, strip = item - slot * kStrips;
-    const int2 own = a.slot_owner[slot];
-    const int chain = __builtin_amdgcn_readfirstlane(own.x), k = __builtin_amdgcn_readfirstlane(own.y);
-    const ChainState *st = a.state + chain;
-    const int64_t wpos = uniform_i64(st->cache_pos + (int64_t)k * st->cache_stride * kHalfFrame);
+    const int slot = slot0 + item / kStrips, strip = item % kStrips;
+    const int chain = __builtin_amdgcn_readfirstlane(a.slot_owner[slot].x);
+    const int64_t wpos = uniform_i64(a.slot_pos[slot]);
     Capture cap;
     cap.iq = a.iq + (int64_t)(chain / 3) * a.ch_stride;
     cap.hist = a.hist ? a.hist + (int64_t)(chain / 3) * a.hist_stride : nullptr;

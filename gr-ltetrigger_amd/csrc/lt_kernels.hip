@@ -623,15 +623,18 @@ __global__ __launch_bounds__(64) void lt_delay_kernel(long long ticks)
 namespace lt {
 
 constexpr int kMaxRounds = 256; // scan rounds per run at most (the per-chain kernel takes what is left)
+constexpr int kCachedScanMaxChannels = 4; // batches up to this size scan from the window cache (lt_batch_set_window_cache 2)
 
 int call_reach() { return kCallReach; }
 int scan_job_bytes() { return (int)sizeof(ScanJob); }
 int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips * kScanMaxRound); }
 int scan_max_round() { return kScanMaxRound; }
 int scan_max_rounds() { return kMaxRounds; }
-int scan_counter_ints() { return 2 * (kMaxRounds + 1) + 3 + 6; } // ... + six diagnostic counts behind it (lt_batch_cache_stats)
-int cache_counter_index() { return 2 * (kMaxRounds + 1) + 2; }
-int scan_counter_ints_legacy() { return 2 * (kMaxRounds + 1) + 3; } // job counters of every round + the per-record work lists' + the window cache's
+// the run's counters: job counters of every round, the two work lists', the window cache's slot counter with six
+// diagnostic counts behind it (lt_batch_cache_stats), the slots handed out per lt_metric_kernel launch
+constexpr int kCtrList = 2 * (kMaxRounds + 1), kCtrSlots = kCtrList + 2, kCtrLaunchSlots = kCtrSlots + 7;
+int scan_counter_ints() { return kCtrLaunchSlots + kMaxRounds + 2; }
+int cache_counter_index() { return kCtrSlots; } // job counters of every round + the per-record work lists' + the window cache's
 int cache_slot_bytes() { return (int)(cache_slot_floats() * sizeof(float)); }
 int cache_max_per_chain() { return kCacheMaxPerChain; }
 int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + 2 * sizeof(int2)); } // CP metrics + one work-list entry for each of the two list slots
@@ -660,6 +663,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
   ScanJob *jobs = reinterpret_cast<ScanJob *>(R.jobs);
   StripPartial *parts = reinterpret_cast<StripPartial *>(R.parts);
   const int64_t t1 = R.t0 + R.n;
+  int n_metric_launches = 0; // lt_metric_kernel launches of the scan rounds (each has its count of slots: launch_slots)
   // ---- rounds of plan, scan, resolve.  An idle chain needs one round per `seg_len` windows; a chain that fires
   // needs a few more (a round ends for it where it re-aligns, where tracking starts, where it is lost).  Rounds
   // with nothing left to do cost three empty launches; whatever a chain has not got through after the last one --
@@ -720,8 +724,26 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     p.n_jobs = R.n_jobs;
     p.jobs_cap = s.jobs_cap = n_chains;
     p.n_counters = scan_counter_ints();
-    p.keep_counter = 2 * (kMaxRounds + 1) + (R.list_slot ? 0 : 1); // the other run's work-list counter (the cache's, behind them, is this run's)
+    p.keep_counter = kCtrList + (R.list_slot ? 0 : 1); // the other run's work-list counter (the cache's, behind them, are this run's)
     p.rebase = R.rebase;
+    // window cache for the scan rounds themselves: batches so small that a channel's strips are alone on their CUs
+    // and a round is bound by a root wave's instruction stream -- without the transforms that stream is 330
+    // instructions instead of 840
+    const bool cached_scan = p.enable && R.cache && R.slot_owner && R.slot_pos && R.slot_cap > 0 && R.cache_level >= 2 &&
+                             R.n_channels <= kCachedScanMaxChannels;
+    p.cached = cached_scan ? 1 : 0;
+    p.slot_owner = reinterpret_cast<int2 *>(R.slot_owner);
+    p.slot_pos = reinterpret_cast<int64_t *>(R.slot_pos);
+    p.slot_next = R.n_jobs + kCtrSlots;
+    p.round_slots = R.n_jobs + kCtrLaunchSlots;
+    p.slot_cap = R.slot_cap;
+    s.cache = cached_scan ? reinterpret_cast<const float *>(R.cache) : nullptr;
+    MetricArgs mm;
+    mm.iq = iq; mm.ch_stride = R.ch_stride; mm.hist = hist; mm.hist_stride = R.hist_stride; mm.t0 = R.t0; mm.n = R.n;
+    mm.hist_len = R.hist_len; mm.slot_owner = p.slot_owner; mm.slot_pos = p.slot_pos; mm.launch_slots = R.n_jobs + kCtrLaunchSlots;
+    mm.slot_cap = R.slot_cap; mm.cache = reinterpret_cast<float *>(R.cache); mm.tab = R.tab;
+    const int metric_grid = 4 * (R.n_cus > 0 ? R.n_cus : 256);
+    n_metric_launches = 0;
     hipLaunchKernelGGL(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
       s.jobs = q.jobs = jobs2[r & 1];
@@ -732,6 +754,12 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       q.next.round_windows = seg_len;
       q.next.jobs = jobs2[(r + 1) & 1];
       q.next.n_jobs = R.n_jobs + 2 * (r + 1);
+      q.next.round_slots = R.n_jobs + kCtrLaunchSlots + (r + 1);
+      if (cached_scan) { // the lag metrics of this round's windows, before its scan
+        mm.n_before = r;
+        hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)metric_grid), dim3(64 * kMetricWaves), 0, stream, mm);
+      }
+      n_metric_launches = cached_scan ? r + 1 : 0;
       if (G == 1) hipLaunchKernelGGL(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
       else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
       else hipLaunchKernelGGL(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
@@ -794,19 +822,22 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.tab = R.tab; c.psr_threshold = R.psr_threshold; c.track_after = R.track_after;
     c.track_every = R.track_every;
     c.list = work_list(R, n_chains);
-    c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
+    c.list_count = R.n_jobs + kCtrList + (R.list_slot ? 1 : 0);
     c.cache = reinterpret_cast<float *>(R.cache);
     c.slot_owner = reinterpret_cast<int2 *>(R.slot_owner);
-    c.slot_next = R.n_jobs + 2 * (kMaxRounds + 1) + 2; // (cleared with the run's other counters by its first launch)
+    c.slot_pos = reinterpret_cast<int64_t *>(R.slot_pos);
+    c.slot_next = R.n_jobs + kCtrSlots; // (cleared with the run's other counters by its first launch)
+    c.launch_slots = R.n_jobs + kCtrLaunchSlots + n_metric_launches;
     c.slot_cap = R.slot_cap;
     c.pass = 0;
-    if (!(c.cache && c.slot_owner && c.slot_cap > 0)) c.cache = nullptr;
+    if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && R.cache_level >= 1)) c.cache = nullptr;
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     if (c.cache) {
       // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
       MetricArgs m;
       m.iq = iq; m.ch_stride = R.ch_stride; m.hist = hist; m.hist_stride = R.hist_stride; m.t0 = R.t0; m.n = R.n;
-      m.hist_len = R.hist_len; m.state = state; m.slot_owner = c.slot_owner; m.slot_next = c.slot_next; m.slot_cap = c.slot_cap;
+      m.hist_len = R.hist_len; m.slot_owner = c.slot_owner; m.slot_pos = c.slot_pos; m.launch_slots = R.n_jobs + kCtrLaunchSlots;
+      m.n_before = n_metric_launches; m.slot_cap = c.slot_cap;
       m.cache = c.cache; m.tab = R.tab;
       const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
       hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);
@@ -830,7 +861,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.hist_len = R.hist_len; c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
     c.metrics = reinterpret_cast<CpMetrics *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
     c.list = work_list(R, n_chains);
-    c.list_count = R.n_jobs + 2 * (kMaxRounds + 1) + (R.list_slot ? 1 : 0);
+    c.list_count = R.n_jobs + kCtrList + (R.list_slot ? 1 : 0);
     SssArgs q;
     q.iq = iq; q.ch_stride = R.ch_stride; q.hist = hist; q.hist_stride = R.hist_stride; q.t0 = R.t0; q.n = R.n;
     q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;

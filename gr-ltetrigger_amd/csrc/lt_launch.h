@@ -50,6 +50,8 @@ struct RunLaunch {
   void *cache = nullptr;      // device, slot_cap x cache_slot_bytes(): the window cache (lag metrics formed in bulk for the chains the
                               // scan rounds leave to the per-chain kernel); null: no cache, the per-chain kernel runs once
   void *slot_owner = nullptr; // device, slot_cap x int2
+  void *slot_pos = nullptr;   // device, slot_cap x int64
+  int cache_level = 2;        // 0 = no cache, 1 = the per-chain kernel's two passes, 2 = also the scan rounds of small batches
   int slot_cap = 0;
   int records_delay_us = 0;   // diagnostics (lt_batch_debug_hold_records): the per-record kernels start this much later
   int list_slot = 0;          // which of the two work lists (and of their counters behind the job counters) this run uses (0 / 1)

@@ -53,6 +53,9 @@ struct ScanJob {
   int32_t channel;
   int32_t n_seq;
   int32_t seq_of_root[3]; // -1: the chain is not served this round
+  int32_t cached;         // the lag metric of every window of the job comes from the window cache (small batches): no
+                          // forward wave, no transforms -- lt_metric_kernel has formed them all before the scan starts
+  int32_t slot_base[3];   // ... chain r's windows in slots slot_base[r] + k, k counted through its sequence's three parts
   int32_t pad;
 };
 // (the job array is written by the kernel before: the compiler reads it with vector loads; its fields are
@@ -113,6 +116,7 @@ struct ScanArgs {
   StripPartial *parts; // [n_channels * 3][kScanMaxRound][12]
   const DeviceTables *tab;
   unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
+  const float *cache;       // window cache (slots of kStrips x 64 * kStripRegs floats), or null
 };
 
 template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups)) void lt_scan_kernel(ScanArgs a)
@@ -148,21 +152,24 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
   const ScanJob *jp = a.jobs + job_i; // (read piecewise: a local copy indexed by sequence would live in scratch)
   const int n_seq = uniform_i32(jp->n_seq), channel = uniform_i32(jp->channel);
   if (n_seq <= 0) return;
+  const bool cached = a.cache != nullptr && uniform_i32(jp->cached) != 0;
   // group g = w % 3 owns strip 3 quarter + g; role w / 3: 0 = forward, 1..3 = root 0..2 (the three forward
   // waves land on three different SIMDs)
   const int g = w % kScanGroups, role = w / kScanGroups;
   const int strip = quarter * kScanGroups + g;
   const int root = role - 1;
   const int my_seq = role ? uniform_i32(jp->seq_of_root[root]) : 0;
-  const bool active = role == 0 || my_seq >= 0;
+  const bool active = (role == 0 && !cached) || (role != 0 && my_seq >= 0);
 
-  for (int i = tid; i < fft::kTw1Len; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
-  if (tid < fft::kTw2Len) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
-  if (tid < kScanGroups * 3) (&sync_ready[0][0])[tid] = (&sync_taken[0][0])[tid] = 0;
+  if (!cached) { // (a cached job has no transforms and no hand-over: nothing to set up, and no barrier -- its forward waves are gone)
+    for (int i = tid; i < fft::kTw1Len; i += kScanThreads) TW1[i] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw1[i]);
+    if (tid < fft::kTw2Len) TW2[tid] = *reinterpret_cast<const fft::c32 *>(a.tab->fft_tw2[tid]);
+    if (tid < kScanGroups * 3) (&sync_ready[0][0])[tid] = (&sync_taken[0][0])[tid] = 0;
 #ifdef LT_SCAN_PROF
-  if (tid < kScanWaves * 8) (&PROF[0][0])[tid] = 0u;
+    if (tid < kScanWaves * 8) (&PROF[0][0])[tid] = 0u;
 #endif
-  __syncthreads(); // tables in place: the only workgroup barrier
+    __syncthreads(); // tables in place: the only workgroup barrier
+  }
   fft::c32 *e = E + w * fft::kScratchW;
 
   Capture cap;
@@ -180,7 +187,9 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
   //   ready[g][q] = windows of sequence q whose first two transform stages the forward wave has left in OUT[g]
   //   taken[g][r] = windows root wave r has read from there (a root wave may be one window ahead of its sequence's others)
   // Hand-over number h (all sequences of the job counted together, in the forward wave's order) uses OUT[g][h & 1].
-  if (role == 0) {
+  if (role == 0 && !active) {
+    // (the forward wave of a cached job: nothing to transform -- and no root wave that would ever release a buffer)
+  } else if (role == 0) {
     // Blocks are fetched one hand-over of their kind ahead, each into the registers the block before has just
     // left (two register sets taking turns for sequence 0, so that no block is ever moved; one for the others'
     // blocks -- chains on windows of their own, 1 <-> 2 in turn).
@@ -256,6 +265,52 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       a.prof[96 + w] = id;
     }
 #endif
+  } else if (active && cached) {
+    // ---- a cached job's root wave: the windows' lag metrics come from the window cache (lt_metric_kernel has formed
+    // them, strip by strip, with the search's own instructions), 14 loads per lane and window, the next window's on
+    // their way while this one's average and peak search run.  No forward wave, no LDS.
+    const ScanSeq sq = uniform_seq(jp->seq[my_seq]);
+    const int n_w = seq_windows(sq);
+    ema_t ema;
+    const int chain = channel * 3 + root;
+    ChainState *st = a.state + chain;
+    const int sel = st->ema_sel;
+    if (sq.zero) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ema[r] = r < kStripRegs ? 0.f : -FLT_MAX;
+    } else {
+      strip_ema_load(st->avg[sel], strip, lane, ema);
+    }
+    StripPartial *parts = a.parts + (int64_t)chain * kScanMaxRound * kStrips + strip;
+    const float *m = a.cache + (size_t)uniform_i32(jp->slot_base[root]) * (kStrips * 64 * kStripRegs) + (size_t)strip * (64 * kStripRegs) + lane;
+    float met[kStripRegs], nxt[kStripRegs];
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) nxt[r] = m[64 * r];
+    for (int k = 0; k < n_w; ++k) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int r = 0; r < kStripRegs; ++r) met[r] = nxt[r];
+      if (k + 1 < n_w) {
+        const float *mn = m + (size_t)(k + 1) * (kStrips * 64 * kStripRegs);
+#pragma unroll
+        for (int r = 0; r < kStripRegs; ++r) nxt[r] = mn[64 * r];
+      }
+      if (k == sq.n_a + sq.n_b && sq.n_c > 0) { // tracking starts here: srslte_pss_reset
+        asm volatile("; the average cleared" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+      }
+      strip_ema_apply(strip, ln, met, ema);
+      if (k < sq.n_a) {
+        if (k == sq.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
+      } else {
+        StripPartial p;
+        strip_resolve(ema, strip, ln, p);
+        if (lane == 0) parts[(int64_t)(k - sq.n_a) * kStrips] = p;
+      }
+    }
+    strip_ema_store(st->avg[(sel + 2) % 3], strip, lane, ema);
   } else if (active) {
     const ScanSeq sq = uniform_seq(jp->seq[my_seq]);
     const int n_w = seq_windows(sq);
@@ -359,6 +414,16 @@ struct PlanArgs {
   int call_reach;    // kCallReach (lt_chain_kernel.h)
   // first launch of a run only (first_round): counters to clear behind n_jobs, the one to leave alone, positions to 0
   int n_counters, keep_counter, rebase;
+  // window cache for the scan rounds (small batches): every job's windows get slots, lt_metric_kernel fills them
+  // before the round's scan.  slot_next counts the slots handed out in this run (it may run past slot_cap: a job that
+  // does not fit stays uncached, and so does every job after it -- the slots in use are always the first ones);
+  // round_slots = those handed out for this round.
+  int cached;
+  int2 *slot_owner;   // [slot_cap]: (chain, window index in its sequence)
+  int64_t *slot_pos;  // [slot_cap]: the window's position
+  int *slot_next;
+  int *round_slots;
+  int slot_cap;
 };
 
 // floor(d / step) for 0 <= d < 2^52, step > 0: through a double-precision quotient and a correction by one (a 64-bit
@@ -371,8 +436,8 @@ __device__ __forceinline__ int64_t div_floor_pos(int64_t d, int64_t step)
   return q;
 }
 
-// the job of channel c for the next round
-__device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
+// the job of channel c for the next round (null: none)
+__device__ __forceinline__ ScanJob *plan_channel(const PlanArgs &a, int c)
 {
   int n[3], stride[3], n_c[3], fresh[3];
   int64_t first[3], pos_c[3];
@@ -467,7 +532,7 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
     len[r] = lead[r] == r ? q[r].n_a + q[r].n_b + q[r].n_c : 0;
   }
   const int longest = len[0] > len[1] ? (len[0] > len[2] ? len[0] : len[2]) : (len[1] > len[2] ? len[1] : len[2]);
-  if (longest == 0) return;
+  if (longest == 0) return nullptr;
   // slot of a leader = the number of leaders that come before it, the longest sequence first (the forward wave
   // prefetches for it and loops over its windows)
   int slot[3];
@@ -504,6 +569,40 @@ __device__ __forceinline__ void plan_channel(const PlanArgs &a, int c)
   job->channel = c;
   job->n_seq = n_seq;
   job->pad = 0;
+  // window cache: slots for the windows of every chain the job serves, or none at all
+  int total = 0, base_r[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    base_r[r] = total;
+    if (lead[r] >= 0) total += len[lead[r]];
+  }
+  int base = -1;
+  if (a.cached && total > 0) {
+    base = atomicAdd(a.slot_next, total);
+    if (base + total > a.slot_cap) base = -1;
+    else atomicAdd(a.round_slots, total);
+  }
+  job->cached = base >= 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) job->slot_base[r] = (base >= 0 && lead[r] >= 0) ? base + base_r[r] : -1;
+  return job;
+}
+
+// The slots of a cached job: who owns each and which window it stands for (all threads of the workgroup that planned
+// the job, after a barrier behind the plan).
+__device__ __forceinline__ void fill_job_slots(const PlanArgs &a, const ScanJob *job, int tid, int nthreads)
+{
+  if (!job->cached) return;
+  for (int r = 0; r < 3; ++r) {
+    const int sq = job->seq_of_root[r];
+    if (sq < 0) continue;
+    const ScanSeq q = job->seq[sq];
+    const int n = seq_windows(q), base = job->slot_base[r];
+    for (int k = tid; k < n; k += nthreads) {
+      a.slot_owner[base + k] = make_int2(job->channel * 3 + r, k);
+      a.slot_pos[base + k] = seq_window_pos(q, k);
+    }
+  }
 }
 
 // The run's first launch: one workgroup.  It first brings the run's counters to zero (the job counters of every round
@@ -519,7 +618,17 @@ __global__ __launch_bounds__(256) void lt_plan_kernel(PlanArgs a)
     __threadfence();
     __syncthreads();
   }
-  for (int c = threadIdx.x; c < a.n_channels; c += 256) plan_channel(a, c);
+  __shared__ ScanJob *planned[256];
+  for (int c0 = 0; c0 < a.n_channels; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    planned[threadIdx.x] = c < a.n_channels ? plan_channel(a, c) : nullptr;
+    if (!a.cached) continue;
+    __threadfence_block();
+    __syncthreads();
+    for (int i = 0; i < 256 && c0 + i < a.n_channels; ++i)
+      if (planned[i]) fill_job_slots(a, planned[i], threadIdx.x, 256);
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------- resolve: general_work on the scanned windows
@@ -888,7 +997,12 @@ __global__ __launch_bounds__(192) void lt_resolve_kernel(ResolveArgs a)
   if (!a.plan_next) return;
   __threadfence_block();
   __syncthreads();
-  if (threadIdx.x == 0) plan_channel(a.next, c);
+  __shared__ ScanJob *planned;
+  if (threadIdx.x == 0) planned = plan_channel(a.next, c);
+  if (!a.next.cached) return;
+  __threadfence_block();
+  __syncthreads();
+  if (planned) fill_job_slots(a.next, planned, threadIdx.x, 192);
 }
 
 } // namespace lt

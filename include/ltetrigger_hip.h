@@ -173,12 +173,14 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
-/* Window cache (default 1).  What the scan rounds leave over -- chains that keep firing and losing a weak cell,
- * every chain in mode 0 -- the per-chain kernel takes in two passes: the first lists the windows every such chain has
- * ahead of it on its present timing, lt_metric_kernel forms their lag metrics for all chains at once, chip-wide, and
- * the second pass runs general_work on them (a window off the list goes through the transforms there and then).
- * 0 = one pass, every search through the transforms.  Same records either way. */
-int lt_batch_set_window_cache(lt_batch *b, int on);
+/* Window cache (default 2).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
+ * cell, every chain in mode 0 -- the per-chain kernel takes in two passes: the first lists the windows every such chain
+ * has ahead of it on its present timing, lt_metric_kernel forms their lag metrics for all chains at once, chip-wide,
+ * and the second pass runs general_work on them (a window off the list goes through the transforms there and then).
+ * Level 2: in batches of up to four channels -- whose scan rounds are bound by the instruction stream of one root
+ * wave per CU, not by the chip -- the rounds' windows are listed too and the scan takes their lag metrics from the cache
+ * (no transforms in the round itself).  0 = every search through the transforms.  Same records at every level. */
+int lt_batch_set_window_cache(lt_batch *b, int level);
 /* Diagnostics of the last run: stats[0] = windows asked for, [1] = searches of the second pass served from the cache,
  * [2] = searches of the second pass that went through the transforms, [3] = chains that waited for the cache,
  * [4] = hits that moved such a chain off the timing its windows were listed on, [5] / [6] = windows a chain's average

@@ -552,6 +552,16 @@ def test_window_cache_gives_the_same_records(lt, oracle, frames_192, mode):
     want = oracle.batch_run(iq, nthreads=8)
     for c in range(18):
         assert_records_match(out[1][c], want[c], f"chain {c}")
+    # a small batch (up to four channels) at level 2, the default: the scan rounds themselves take their lag metrics
+    # from the cache -- the first three channels' records are those they have in the batch of six
+    if mode == 1:
+        for level in (2, 1):
+            b = lt.Batch(3, iq.shape[1])
+            b.set_window_cache(level)
+            b.run_host(iq[:3])
+            got = b.collect()
+            for c in range(9):
+                assert got[c].tobytes() == out[0][c].tobytes(), f"level {level} chain {c}"
 
 
 @pytest.mark.parametrize("mode", [1, 0])

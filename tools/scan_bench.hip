@@ -94,6 +94,7 @@ int main(int argc, char **argv)
   CK(hipMalloc(&dprof, 8 * 128));
   CK(hipMemset(dprof, 0, 8 * 128));
   a.prof = dprof;
+  a.cache = nullptr;
   const int G = argc > 5 ? atoi(argv[5]) : 3; // strips per workgroup
   const int grid = ((n_ch * scan_wg_per_job(G) + 7) / 8) * 8;
   hipEvent_t e0, e1;
