@@ -119,6 +119,17 @@ struct ScanArgs {
   const float *cache;       // window cache (slots of kStrips x 64 * kStripRegs floats), or null
 };
 
+#ifndef LT_PRIO_F_IDLE
+#define LT_PRIO_F_IDLE 1
+#endif
+__device__ __forceinline__ void set_wave_priority(int p)
+{
+  if (p <= 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
+
 template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups)) void lt_scan_kernel(ScanArgs a)
 {
   constexpr int kScanWaves = scan_waves(kScanGroups), kScanThreads = scan_threads(kScanGroups), kScanWgPerJob = scan_wg_per_job(kScanGroups);
@@ -219,10 +230,22 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       LT_FSTAMP(1) // first stage (and the wait for the block's samples)
       // the block that used this buffer two hand-overs ago has been taken by all its root waves
       const int hr = (h & 1) ? held_roots1 : held_roots0, hn = (h & 1) ? held_need1 : held_need0;
+      bool waited = false;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         if ((hr >> r) & 1)
-          while (__hip_atomic_load(&sync_taken[g][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hn) __builtin_amdgcn_s_sleep(LT_POLL_SLEEP);
+          while (__hip_atomic_load(&sync_taken[g][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hn) {
+            waited = true;
+            __builtin_amdgcn_s_sleep(LT_POLL_SLEEP);
+          }
+      // Issue priority (s_setprio).  Three waves share a SIMD and the arbiter serves the oldest first: left alone, the wave
+      // in a SIMD's third slot gets what the other two leave, its strip falls behind and the workgroup waits for it at the
+      // end.  A forward wave that finds its buffer taken already is what its root waves wait for: first in line; one
+      // that had to wait has time to spare.
+      if constexpr (kScanGroups == 3) {
+        if (waited) __builtin_amdgcn_s_setprio(LT_PRIO_F_IDLE);
+        else __builtin_amdgcn_s_setprio(3);
+      }
       LT_FSTAMP(2) // waiting for the buffer
       LT_LDS_ORDER;
       fft::fft1024w_stageB<false>(ln, x, TW2, e, OUT[g][h & 1]);
@@ -351,6 +374,14 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       __builtin_amdgcn_sched_barrier(0);
       const int hk = k + (k < n1 ? k : n1) + (k < n2 ? k : n2) + (my_seq >= 1) + (my_seq >= 2 && k < n1);
       const fft::c32 *e_fwd = OUT[g][hk & 1];
+      if constexpr (kScanGroups == 3) {
+        // ... and the workgroup's three strips should finish together: a root wave measures itself against its root's
+        // waves of the other two strips (windows taken so far) -- behind them it moves up, ahead of both it steps back
+        const int p1 = uniform_i32(__hip_atomic_load(&sync_taken[(g + 1) % 3][root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const int p2 = uniform_i32(__hip_atomic_load(&sync_taken[(g + 2) % 3][root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const int behind = (k < p1) + (k < p2), ahead = (k > p1) + (k > p2);
+        set_wave_priority(1 + behind - (ahead == 2 ? 1 : 0));
+      }
       while (__hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(LT_POLL_SLEEP);
       LT_LDS_ORDER;
       LT_PSTAMP(0) // waiting for the forward wave
