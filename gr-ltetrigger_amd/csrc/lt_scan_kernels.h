@@ -119,9 +119,6 @@ struct ScanArgs {
   const float *cache;       // window cache (slots of kStrips x 64 * kStripRegs floats), or null
 };
 
-#ifndef LT_PRIO_F_IDLE
-#define LT_PRIO_F_IDLE 1
-#endif
 __device__ __forceinline__ void set_wave_priority(int p)
 {
   if (p <= 0) __builtin_amdgcn_s_setprio(0);
@@ -243,7 +240,8 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       // end.  A forward wave that finds its buffer taken already is what its root waves wait for: first in line; one
       // that had to wait has time to spare.
       if constexpr (kScanGroups == 3) {
-        if (waited) __builtin_amdgcn_s_setprio(LT_PRIO_F_IDLE);
+        // (with three window sequences the forward wave transforms three blocks per window: always what the others wait for)
+        if (waited && n_seq < 3) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(3);
       }
       LT_FSTAMP(2) // waiting for the buffer
