@@ -2,6 +2,7 @@
 # Collects the round's measurement artefacts on the GPU box (one gpurun call):
 #   bash tools/collect_artifacts.sh r03        -> gpurun_out/final/r03_*
 # Every step is checked: a failed step stops the script (no ALLDONE, no stale copies).
+# Before the call, here: make -C gr-ltetrigger_amd all scan_bench   (the box runs the binaries it is sent)
 set -euo pipefail
 TAG="${1:-r03}"
 : "${GRAFT_REPO_ROOT:?must run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
@@ -23,8 +24,9 @@ cp gpurun_out/pmc/traffic.json "$OUT/traffic.json"
 bash tools/pmc_scan.sh gr-ltetrigger_amd/build/scan_bench lt_scan_kernel 64 64 7 1 > "$OUT/${TAG}_pmc_scan_kernel.txt" 2>&1
 for a in "64 64 7 1" "64 64 3 1" "64 64 1 1" "64 64 7 2" "64 64 7 3"; do
   echo "== scan_bench $a"
-  gr-ltetrigger_amd/build/scan_bench $a 2>&1 | grep "^scan\|checksum" | tail -2
+  { gr-ltetrigger_amd/build/scan_bench $a 2>&1 | grep "^scan\|checksum" | tail -2; } 2>/dev/null
 done > "$OUT/${TAG}_scan_bench.txt" 2>&1
+gr-ltetrigger_amd/build/scan_bench_prof 64 64 7 1 > "$OUT/${TAG}_scan_phases.txt" 2>&1
 timeout -k 10 500 python tools/stress_parity.py --scenes 400 --seed0 9000 --out "$OUT/stress" > "$OUT/stress.json" 2> "$OUT/stress.err"
 cp "$OUT/stress/stress_parity.json" "$OUT/${TAG}_stress_parity.json"
 echo ALLDONE
