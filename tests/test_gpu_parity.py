@@ -141,6 +141,24 @@ def test_decimator_bit_exact(lt, oracle, decim):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("decim", [4, 8, 16])
+def test_decimator_reference_rates_ragged_lengths(lt, oracle, decim):
+    """The reference's rates (compile-time rate in the kernel): input lengths that are no multiple of the rate or of a
+    block's outputs, shorter than the filter, and several channels at once -- bit for bit the oracle's tap-ordered
+    sums."""
+    rng = np.random.default_rng(100 + decim)
+    dec = lt.Decim(decim)
+    for n in (1, decim - 1, decim, 3 * decim + 1, 777, 2048 * decim - 1, 2048 * decim + decim + 5, 70001):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        got, want = dec.run_host(x), oracle.decimate(x, decim)
+        assert got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"decim {decim} n {n}"
+    x = (rng.standard_normal((3, 40000)) + 1j * rng.standard_normal((3, 40000))).astype(np.complex64)
+    got = dec.run_host(x)
+    for c in range(3):
+        assert np.array_equal(got[c].view(np.uint32), oracle.decimate(x[c], decim).view(np.uint32)), f"channel {c}"
+
+
 @pytest.mark.parametrize("decim", [2, 3, 5, 12])
 def test_decimator_other_rates_and_ragged_lengths(lt, oracle, decim):
     """Rates outside the reference's 4 / 8 / 16 take the kernel's generic path; input lengths that are
