@@ -125,8 +125,10 @@ def self_launch(args):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (defaults long enough for the GPU's clock to have settled: it climbs for ~20 ms after the first launches of a
+    # loaded queue -- the same step takes 0.93 ms in a run of 2 + 10 steps, 0.87 ms in 5 + 20, 0.80 ms from step ~40 on)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
     ap.add_argument("--seconds", type=float, default=1.0, help="capture length per channel")
     ap.add_argument("--snr-db", type=float, default=20.0)
@@ -140,6 +142,7 @@ def parse_args(argv=None):
                          "next step's scan rounds (default: off, the library's default; the bench line carries that "
                          "measurement as an extra leg either way)")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra overlapped measurement")
+    ap.add_argument("--no-steady-leg", action="store_true", help="skip the extra measurement with the clock settled")
     ap.add_argument("--scan-segments", default="", help="first,later: lt_batch_set_scan_segments (windows per scan segment)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the cpu_baseline (0 = the box's CPU share for one GPU: min(available, 16))")
@@ -202,11 +205,8 @@ def main():
     n = int(round(args.seconds * FS))
     frames = base_frames(lt)
     my_channels = sharding.channel_range(rank, world, n_ch)
-    iq, expect = make_channels(torch, frames, n_ch, n, my_channels[0], args.snr_db, dev)
-    iq_real = torch.view_as_real(iq)
-    assert iq_real.is_contiguous()
-    torch.cuda.synchronize()
-
+    # (the batch and its buffers first, the input last: the allocations leave the GPU idle for tens of milliseconds, and
+    # what follows the input's generation is the warm-up)
     batch = lt.Batch(n_ch, n, psr_threshold=4.0, device=local_rank)
     batch.set_mode(args.mode)
     batch.set_overlap(args.overlap)
@@ -217,6 +217,11 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     assert stream != 0
+
+    iq, expect = make_channels(torch, frames, n_ch, n, my_channels[0], args.snr_db, dev)
+    iq_real = torch.view_as_real(iq)
+    assert iq_real.is_contiguous()
+    torch.cuda.synchronize()
 
     def step():
         batch.reset()
@@ -270,18 +275,46 @@ def main():
 
     # correctness of what was timed: cell_id match on this rank's channels
     recs = batch.collect()
+    # extra leg: the same steps once the clock has settled -- whatever --warmup / --steps were, the 50 steps timed here
+    # start at least 150 steps after the first one of this process (the overlapped leg below runs after them)
+    steady_leg = None
+    if not args.overlap and not args.no_steady_leg and args.steps > 0:
+        done = args.warmup + args.steps + n_inst
+        for _ in range(max(0, 150 - done)):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_st = sharding.max_over_ranks(dist, torch, time.perf_counter() - t2, dev)
+        recs_st = batch.collect()
+        v_st = sharding.aggregate_msamp_per_s(world, n_ch, n, 50, dt_st)
+        steady_leg = {"value": round(v_st, 3), "unit": "Msamp/s", "steps": 50, "ms_per_step": round(dt_st / 50 * 1e3, 4),
+                      "frac": round(v_st * 1e6 * ALGO_BYTES_PER_SAMPLE / world / 1e9 / HBM_PEAK_GBS, 5),
+                      "steps_before": max(150, done),
+                      "records_identical": all(a.tobytes() == b_.tobytes() for a, b_ in zip(recs, recs_st)),
+                      "what": "the same steps, timed the same way, after at least 150 steps of this process: the GPU's clock climbs "
+                              "for ~20 ms once its queue is loaded, and `value` is the rate of the steps --warmup / --steps name, "
+                              "wherever on that climb they fall"}
     # extra leg: the same steps with the other overlap setting's counterpart (lt_batch_set_overlap(1)): per-record kernels
     # of step i beside the scan rounds of step i + 1; every step's records complete inside the timed region
     overlap_leg = None
     if not args.overlap and not args.no_overlap_leg and args.steps > 0:
         batch.set_overlap(True)
-        for _ in range(2):
+        # (switching allocates the second set of records: the queue runs dry and the clock falls back -- 50 untimed steps,
+        # then 50 timed ones, like the steady-state leg this one is to be read against)
+        for _ in range(50):
             step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(50):
             step()
         torch.cuda.synchronize()
         if world > 1:
@@ -290,10 +323,11 @@ def main():
         recs_ov = batch.collect()
         same_ov = all(a.tobytes() == b_.tobytes() for a, b_ in zip(recs, recs_ov))
         batch.set_overlap(False)
-        overlap_leg = {"value": round(sharding.aggregate_msamp_per_s(world, n_ch, n, args.steps, dt_ov), 3), "unit": "Msamp/s",
-                       "ms_per_step": round(dt_ov / args.steps * 1e3, 4), "records_identical": bool(same_ov),
+        overlap_leg = {"value": round(sharding.aggregate_msamp_per_s(world, n_ch, n, 50, dt_ov), 3), "unit": "Msamp/s", "steps": 50,
+                       "ms_per_step": round(dt_ov / 50 * 1e3, 4), "records_identical": bool(same_ov),
                        "what": "lt_batch_set_overlap(1): a step's per-record kernels (CFO, CP, SSS) on a second, low-priority stream "
-                               "beside the next step's scan rounds; same steps, every step's records complete inside the timed region"}
+                               "beside the next step's scan rounds; same steps, every step's records complete inside the timed region; "
+                               "50 steps after 50 untimed ones: to be read against `steady_state`"}
     cache_stats = batch.cache_stats()
     found = cells_found(lt, recs, n_ch)
     ok = sum(1 for c in range(n_ch)
@@ -387,6 +421,8 @@ def main():
         }
         if overlap_leg is not None:
             out["overlapped"] = overlap_leg
+        if steady_leg is not None:
+            out["steady_state"] = steady_leg
         # the side measurements run at N = 1 only (rank 0 would keep the other ranks waiting at the last barrier)
         if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(torch, lt, iq, n_ch, n, local_rank)
