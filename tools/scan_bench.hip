@@ -100,7 +100,8 @@ int main(int argc, char **argv)
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int it = 0; it < 4; ++it) {
+  const int n_iter = argc > 6 ? atoi(argv[6]) : 4; // launches (the GPU's clock settles after ~20 ms of them)
+  for (int it = 0; it < n_iter; ++it) {
     CK(hipEventRecord(e0));
     if (G == 1) hipLaunchKernelGGL(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, 0, a);
     else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, 0, a);
@@ -110,7 +111,7 @@ int main(int argc, char **argv)
     CK(hipGetLastError());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("scan %d ch x %d windows: %.3f ms  (%.1f Gsamp/s, %.3f of 8 TB/s at 8 B/sample)\n", n_ch, n_win, ms,
+    if (it < 4 || it + 2 >= n_iter) printf("scan %d ch x %d windows: %.3f ms  (%.1f Gsamp/s, %.3f of 8 TB/s at 8 B/sample)\n", n_ch, n_win, ms,
            (double)n_ch * n / ms * 1e-6, (double)n_ch * n * 8 / (ms * 1e-3) / 8e12);
   }
 #ifdef LT_SCAN_PROF
