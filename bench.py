@@ -58,25 +58,36 @@ def base_frames(lt):
 
 
 def make_channels(torch, frames, n_channels, n_samples, first_channel, snr_db, dev):
-    """Seeded per global channel index; see tests/siggen.py for the numpy twin of this generator."""
+    """Seeded per global channel index; see tests/siggen.py for the numpy twin of this generator.  The noise of every
+    channel first (one generator each), then the channels of a fixture together: a few large launches rather than
+    six small ones per channel."""
     iq = torch.empty((n_channels, n_samples), dtype=torch.complex64, device=dev)
+    iq_real = torch.view_as_real(iq)
     expect = np.full(n_channels, -1, np.int64)
-    t = torch.arange(n_samples, device=dev)
     for c in range(n_channels):
-        gc = first_channel + c
         g = torch.Generator(device=dev)
-        g.manual_seed(1000 + gc)
-        frame, cid = frames[gc % len(frames)]
+        g.manual_seed(1000 + first_channel + c)
+        torch.randn((n_samples, 2), generator=g, device=dev, dtype=torch.float32, out=iq_real[c])
+    t = torch.arange(n_samples, device=dev)
+    by_fixture = {}
+    for c in range(n_channels):
+        by_fixture.setdefault((first_channel + c) % len(frames), []).append(c)
+    for f, chans in by_fixture.items():
+        frame, cid = frames[f]
         fr = torch.from_numpy(frame).to(dev)
         p_sig = float(np.mean(np.abs(frame) ** 2))
-        rot = int(np.random.default_rng(gc).integers(0, frame.size))
-        noise = torch.randn((n_samples, 2), generator=g, device=dev, dtype=torch.float32)
-        noise = torch.view_as_complex(noise)
-        if gc % 8 == 7:
-            iq[c] = noise * np.sqrt(p_sig / 2.0)
-            continue
-        iq[c] = fr[(t + rot) % frame.size] + noise * np.sqrt(p_sig / (10.0 ** (snr_db / 10.0)) / 2.0)
-        expect[c] = cid
+        idle = [c for c in chans if (first_channel + c) % 8 == 7]
+        live = [c for c in chans if (first_channel + c) % 8 != 7]
+        if idle:
+            ii = torch.tensor(idle, device=dev)
+            iq[ii] = iq[ii] * np.sqrt(p_sig / 2.0)
+        if live:
+            li = torch.tensor(live, device=dev)
+            rot = torch.tensor([int(np.random.default_rng(first_channel + c).integers(0, frame.size)) for c in live], device=dev)
+            sig = fr[(t[None, :] + rot[:, None]) % frame.size]
+            iq[li] = sig + iq[li] * np.sqrt(p_sig / (10.0 ** (snr_db / 10.0)) / 2.0)
+            for c in live:
+                expect[c] = cid
     return iq, expect
 
 
