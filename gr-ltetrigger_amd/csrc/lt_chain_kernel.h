@@ -300,6 +300,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
   int n_emits = 0;
   int buf = 0;
   bool searched = false; // the registers hold the chain's average (a search has run)
+  bool stop_run = false; // the stream ends inside the half-frame a call would emit: no further call in this run
   __syncthreads();
   // One record: everything the sss side adds (CFO, CP, SSS: lt_kernels.hip, per record) starts out empty.
   auto put_record = [&](int idx, int64_t in_pos, int64_t out_pos, uint32_t flags, int used_peak, int sc, float ps, float pv, float pmax, int tm) {
@@ -426,7 +427,12 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       peak_pos = kSlotLen;
       const int64_t hf0 = pos + frame_start;
       if (cache_n > 0 && frame_start != 0 && tid == 0) atomicAdd(a.slot_next + 4, 1); // diagnostics
-      if (hf0 + kHalfFrame > t1) break; // (flush only) quirk q1 normalised: never read past the capture
+      if (hf0 + kHalfFrame > t1) { // (flush only) quirk q1 normalised: never read past the capture
+        // (the chain is through for this run -- and must stay so: the second pass of a two-pass run would take the call
+        // up again, from an average this search has already gone into)
+        stop_run = true;
+        break;
+      }
       next_pos = hf0 + kHalfFrame;
       out_pos = hf0;
       flags |= LT_F_EMITTED;
@@ -467,6 +473,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       st->pre_n = 0;
     }
     a.rec_count[chain] = nrec;
+    if (stop_run) st->run_done = 1;
   }
 }
 

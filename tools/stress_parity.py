@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--seed0", type=int, default=5000)
     ap.add_argument("--out", default=None)
     ap.add_argument("--replay", default=None, help="an .npz written by an earlier run")
+    ap.add_argument("--scan-groups", type=int, default=0,
+                    help="strips per scan workgroup (lt_batch_set_scan_groups): 0 = as the batch size chooses (one for scenes this small), "
+                         "3 = the benchmark's shape (hand-over between waves that share SIMDs, issue priorities)")
     args = ap.parse_args()
 
     import torch  # noqa: F401  (first: see ltetrigger_amd._binding.lib)
@@ -96,6 +99,7 @@ def main():
         for mode in (1, 0):
             b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
             b.set_mode(mode)
+            b.set_scan_groups(args.scan_groups)
             b.run_host(iq)
             got = b.collect()
             b.close()
@@ -119,7 +123,7 @@ def main():
                     break
         if n_scenes % 20 == 0:
             print(f"{n_scenes} scenes, {len(bad)} differ, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
-    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0],
+    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups,
            "differing": bad, "arg_max_between_lags_equal_to_1e-4": ties, "seconds": round(time.time() - t_start, 1)}
     print(json.dumps(res))
     if args.out:
