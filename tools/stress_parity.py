@@ -55,6 +55,12 @@ def main():
     ap.add_argument("--seed0", type=int, default=5000)
     ap.add_argument("--out", default=None)
     ap.add_argument("--replay", default=None, help="an .npz written by an earlier run")
+    ap.add_argument("--chunks", action="store_true",
+                    help="feed every scene as a stream cut at random positions (lt_batch_push; 2 to 7 chunks, some shorter than a "
+                         "half-frame), the records of all pushes together against the oracle's single run")
+    ap.add_argument("--variants", type=int, default=0,
+                    help="per scene, this many more runs with a random execution mode, window-cache level, workgroup shape and "
+                         "round lengths: their records bit for bit those of the default run")
     ap.add_argument("--scan-groups", type=int, default=0,
                     help="strips per scan workgroup (lt_batch_set_scan_groups): 0 = as the batch size chooses (one for scenes this small), "
                          "3 = the benchmark's shape (hand-over between waves that share SIMDs, issue priorities)")
@@ -92,6 +98,7 @@ def main():
     n_records = 0
     n_samples = 0
     n_scenes = 0
+    n_variants = 0
     for seed, iq, kw in scenes():
         want = O.batch_run(iq, nthreads=min(os.cpu_count() or 1, 16), **kw)
         n_scenes += 1
@@ -100,8 +107,22 @@ def main():
             b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
             b.set_mode(mode)
             b.set_scan_groups(args.scan_groups)
-            b.run_host(iq)
-            got = b.collect()
+            if args.chunks:
+                r = np.random.default_rng(seed * 7 + mode)
+                n = iq.shape[1]
+                cuts = np.sort(r.choice(np.arange(1, n), size=int(r.integers(1, 7)), replace=False))
+                if r.integers(0, 3) == 0:
+                    cuts = np.sort(np.unique(np.clip(np.concatenate([cuts, cuts[:1] + int(r.integers(1, 300)), [n - int(r.integers(1, 9000))]]), 1, n - 1)))
+                edges = [0] + [int(c) for c in cuts] + [n]
+                parts = [[] for _ in range(3 * iq.shape[0])]
+                for i in range(len(edges) - 1):
+                    b.push_host(np.ascontiguousarray(iq[:, edges[i]:edges[i + 1]]), end_of_stream=(edges[i + 1] == n))
+                    for c, recs in enumerate(b.collect()):
+                        parts[c].append(recs.copy())
+                got = [np.concatenate(p) for p in parts]
+            else:
+                b.run_host(iq)
+                got = b.collect()
             b.close()
             for c in range(len(want)):
                 n_records += len(want[c])
@@ -121,9 +142,37 @@ def main():
                         os.makedirs(args.out, exist_ok=True)
                         np.savez(os.path.join(args.out, f"scene_{seed}.npz"), iq=iq[c // 3:c // 3 + 1], kw=kw)
                     break
+        if args.variants and not args.chunks:
+            b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+            b.set_scan_groups(args.scan_groups)
+            b.run_host(iq)
+            ref = [r.copy() for r in b.collect()]
+            b.close()
+            r = np.random.default_rng(seed * 13 + 5)
+            for k in range(args.variants):
+                v = {"mode": int(r.integers(0, 2)), "cache": int(r.integers(0, 3)), "groups": int(r.integers(0, 4)),
+                     "segments": [None, (1, 5), (2, 32), (64, 64), (3, 128), (1, 1)][int(r.integers(0, 6))]}
+                b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+                b.set_mode(v["mode"])
+                b.set_window_cache(v["cache"])
+                b.set_scan_groups(v["groups"])
+                if v["segments"]:
+                    b.set_scan_segments(*v["segments"])
+                b.run_host(iq)
+                other = b.collect()
+                b.close()
+                n_variants += 1
+                for c in range(len(ref)):
+                    if other[c].tobytes() != ref[c].tobytes():
+                        bad.append({"seed": seed, "variant": v, "chain": c, "kw": kw, "what": "records differ from the default run's"})
+                        print(json.dumps(bad[-1]), file=sys.stderr, flush=True)
+                        if args.out and len(bad) <= 3 and not args.replay:
+                            os.makedirs(args.out, exist_ok=True)
+                            np.savez(os.path.join(args.out, f"scene_{seed}.npz"), iq=iq, kw=kw)
+                        break
         if n_scenes % 20 == 0:
             print(f"{n_scenes} scenes, {len(bad)} differ, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
-    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups,
+    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups, "chunks": bool(args.chunks), "variant_runs": n_variants,
            "differing": bad, "arg_max_between_lags_equal_to_1e-4": ties, "seconds": round(time.time() - t_start, 1)}
     print(json.dumps(res))
     if args.out:
