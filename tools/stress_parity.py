@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--chunks", action="store_true",
                     help="feed every scene as a stream cut at random positions (lt_batch_push; 2 to 7 chunks, some shorter than a "
                          "half-frame), the records of all pushes together against the oracle's single run")
+    ap.add_argument("--overlap-runs", type=int, default=0,
+                    help="per scene, this many runs back to back on the capture in device memory (no reset in between: every run "
+                         "carries the state of the one before) with lt_batch_set_overlap(1), each run's records fetched one run "
+                         "behind (lt_batch_collect_previous): bit for bit those of the same sequence without overlap")
     ap.add_argument("--variants", type=int, default=0,
                     help="per scene, this many more runs with a random execution mode, window-cache level, workgroup shape and "
                          "round lengths: their records bit for bit those of the default run")
@@ -142,6 +146,44 @@ def main():
                         os.makedirs(args.out, exist_ok=True)
                         np.savez(os.path.join(args.out, f"scene_{seed}.npz"), iq=iq[c // 3:c // 3 + 1], kw=kw)
                     break
+        if args.overlap_runs and not args.chunks:
+            import torch
+            dev = torch.device("cuda", 0)
+            d_iq = torch.from_numpy(iq).to(dev)
+            st = torch.cuda.Stream(dev)
+            torch.cuda.synchronize()
+            n = iq.shape[1]
+            r = np.random.default_rng(seed * 17 + 3)
+            mode = int(r.integers(0, 2))
+            seqs = {}
+            for ov in (0, 1):
+                b = lt.Batch(iq.shape[0], n, **kw)
+                b.set_mode(mode)
+                b.set_scan_groups(args.scan_groups)
+                b.set_overlap(bool(ov))
+                if ov and r.integers(0, 2):
+                    b.debug_hold_records(int(r.integers(100, 3000)))
+                per_run = []
+                for k in range(args.overlap_runs):
+                    b.run_device(torch.view_as_real(d_iq).data_ptr(), n, st.cuda_stream)
+                    if ov and k > 0:
+                        per_run.append([x.copy() for x in b.collect_previous()])
+                    elif not ov:
+                        per_run.append([x.copy() for x in b.collect()])
+                if ov:
+                    per_run.append([x.copy() for x in b.collect()])
+                seqs[ov] = per_run
+                b.close()
+            n_variants += args.overlap_runs
+            for k in range(args.overlap_runs):
+                for c in range(3 * iq.shape[0]):
+                    if seqs[0][k][c].tobytes() != seqs[1][k][c].tobytes():
+                        bad.append({"seed": seed, "mode": mode, "run": k, "chain": c, "kw": kw, "what": "overlapped run's records differ from the plain sequence's"})
+                        print(json.dumps(bad[-1]), file=sys.stderr, flush=True)
+                        break
+                else:
+                    continue
+                break
         if args.variants and not args.chunks:
             b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
             b.set_scan_groups(args.scan_groups)
