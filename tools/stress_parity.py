@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--chunks", action="store_true",
                     help="feed every scene as a stream cut at random positions (lt_batch_push; 2 to 7 chunks, some shorter than a "
                          "half-frame), the records of all pushes together against the oracle's single run")
+    ap.add_argument("--stack", type=int, default=1,
+                    help="this many random scenes (3 to 11 channels each) stacked into one batch, cut to the shortest, with the first "
+                         "one's parameters: 7 -> ~50 channels (three strips per scan workgroup), 14 -> ~100 (more workgroups than CUs)")
     ap.add_argument("--overlap-runs", type=int, default=0,
                     help="per scene, this many runs back to back on the capture in device memory (no reset in between: every run "
                          "carries the state of the one before) with lt_batch_set_overlap(1), each run's records fetched one run "
@@ -94,6 +97,10 @@ def main():
             lo, hi = [(25, 45), (60, 140), (130, 260)][wide]
             snr = [(-6.0, 6.0), (-2.0, 25.0)][int(rng.integers(0, 2))]
             iq, kw = siggen.random_scene(seed, frames, names, lo, hi, snr)
+            if args.stack > 1:
+                more = [siggen.random_scene(seed * 1000 + j, frames, names, lo, hi, snr)[0] for j in range(1, args.stack)]
+                n = min([iq.shape[1]] + [m.shape[1] for m in more])
+                iq = np.ascontiguousarray(np.concatenate([iq[:, :n]] + [m[:, :n] for m in more]))
             yield seed, iq, kw
 
     t_start = time.time()
@@ -214,7 +221,7 @@ def main():
                         break
         if n_scenes % 20 == 0:
             print(f"{n_scenes} scenes, {len(bad)} differ, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
-    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups, "chunks": bool(args.chunks), "variant_runs": n_variants,
+    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups, "chunks": bool(args.chunks), "stack": args.stack, "variant_runs": n_variants,
            "differing": bad, "arg_max_between_lags_equal_to_1e-4": ties, "seconds": round(time.time() - t_start, 1)}
     print(json.dumps(res))
     if args.out:
