@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--chunks", action="store_true",
                     help="feed every scene as a stream cut at random positions (lt_batch_push; 2 to 7 chunks, some shorter than a "
                          "half-frame), the records of all pushes together against the oracle's single run")
+    ap.add_argument("--windows", default="", help="lo,hi: capture lengths of lo .. hi - 1 whole windows plus a fraction (default: a third each of 25-45, 60-140, 130-260)")
     ap.add_argument("--stack", type=int, default=1,
                     help="this many random scenes (3 to 11 channels each) stacked into one batch, cut to the shortest, with the first "
                          "one's parameters: 7 -> ~50 channels (three strips per scan workgroup), 14 -> ~100 (more workgroups than CUs)")
@@ -96,7 +97,11 @@ def main():
             wide = int(rng.integers(0, 3))  # a third each: short, several rounds, long
             lo, hi = [(25, 45), (60, 140), (130, 260)][wide]
             snr = [(-6.0, 6.0), (-2.0, 25.0)][int(rng.integers(0, 2))]
+            if args.windows:
+                lo, hi = [int(v) for v in args.windows.split(",")]
             iq, kw = siggen.random_scene(seed, frames, names, lo, hi, snr)
+            if iq.shape[1] == 0:
+                continue
             if args.stack > 1:
                 more = [siggen.random_scene(seed * 1000 + j, frames, names, lo, hi, snr)[0] for j in range(1, args.stack)]
                 n = min([iq.shape[1]] + [m.shape[1] for m in more])
@@ -115,7 +120,7 @@ def main():
         n_scenes += 1
         n_samples += iq.size
         for mode in (1, 0):
-            b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+            b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
             b.set_mode(mode)
             b.set_scan_groups(args.scan_groups)
             if args.chunks:
@@ -164,7 +169,7 @@ def main():
             mode = int(r.integers(0, 2))
             seqs = {}
             for ov in (0, 1):
-                b = lt.Batch(iq.shape[0], n, **kw)
+                b = lt.Batch(iq.shape[0], max(n, 9600), **kw)
                 b.set_mode(mode)
                 b.set_scan_groups(args.scan_groups)
                 b.set_overlap(bool(ov))
@@ -192,7 +197,7 @@ def main():
                     continue
                 break
         if args.variants and not args.chunks:
-            b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+            b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
             b.set_scan_groups(args.scan_groups)
             b.run_host(iq)
             ref = [r.copy() for r in b.collect()]
@@ -201,7 +206,7 @@ def main():
             for k in range(args.variants):
                 v = {"mode": int(r.integers(0, 2)), "cache": int(r.integers(0, 3)), "groups": int(r.integers(0, 4)),
                      "segments": [None, (1, 5), (2, 32), (64, 64), (3, 128), (1, 1)][int(r.integers(0, 6))]}
-                b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+                b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
                 b.set_mode(v["mode"])
                 b.set_window_cache(v["cache"])
                 b.set_scan_groups(v["groups"])
