@@ -250,15 +250,21 @@ def main():
 
     # (device time per run and per stage: the library's own HIP events on the launch stream, lt_batch_phase_ms below;
     # a second pair of events around every run would cost the timed region another ~10 us per step)
+    # (... but one pair of HIP events around the whole timed region, on the stream the kernels are launched on, costs it
+    # nothing to speak of: `roofline.timed_region_ms_per_step`, the GPU's own clock on the very steps `value` is the rate of)
+    ev_t0, ev_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_t0.record(tstream)
     for k in range(args.steps):
         batch.reset()
         batch.run_device(iq_real.data_ptr(), n, stream)
+    ev_t1.record(tstream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed_region_ms = ev_t0.elapsed_time(ev_t1) / max(args.steps, 1)
 
     elapsed = sharding.max_over_ranks(dist, torch, elapsed, dev)
     if args.steps <= 0:
@@ -406,7 +412,9 @@ def main():
             "realtime_factor": round(value * 1e6 / (world * n_ch * FS), 2),
             # algorithmic bytes = 8 B per input sample, whatever a kernel spills on top.
             # achieved / frac = those bytes / the wall time of a step of the timed region (= `value` x 8 B: reset, every launch of
-            # the run, the gaps between runs); `device_*` = the same against the run's launches alone (first to last, by the
+            # the run, the gaps between runs); `timed_region_*` = the same steps by a pair of HIP events on the launch stream
+            # around the whole timed region (in overlap mode the per-record kernels of the last step, on their own stream,
+            # end after the second event); `device_*` = the same against the run's launches alone (first to last, by the
             # library's HIP events on the launch stream); `stage_*` = against the dominant stage alone (the scan rounds:
             # lt_plan_kernel + lt_scan_kernel + lt_resolve_kernel launches).
             "roofline": {
@@ -417,6 +425,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                "timed_region_ms_per_step": round(timed_region_ms, 4),
+                "timed_region_frac": round(algo_bytes / (timed_region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "device_ms": round(kernel_ms, 4),
                 "device_achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 2),
                 "device_frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
