@@ -59,6 +59,9 @@ def main():
                     help="feed every scene as a stream cut at random positions (lt_batch_push; 2 to 7 chunks, some shorter than a "
                          "half-frame), the records of all pushes together against the oracle's single run")
     ap.add_argument("--windows", default="", help="lo,hi: capture lengths of lo .. hi - 1 whole windows plus a fraction (default: a third each of 25-45, 60-140, 130-260)")
+    ap.add_argument("--halfframes", action="store_true",
+                    help="per scene, the emitted half-frames of every chain of one random channel (lt_batch_enable_halfframes: the pss "
+                         "block's output stream, CFO-corrected while tracking) bit for bit the oracle's")
     ap.add_argument("--stack", type=int, default=1,
                     help="this many random scenes (3 to 11 channels each) stacked into one batch, cut to the shortest, with the first "
                          "one's parameters: 7 -> ~50 channels (three strips per scan workgroup), 14 -> ~100 (more workgroups than CUs)")
@@ -158,6 +161,25 @@ def main():
                         os.makedirs(args.out, exist_ok=True)
                         np.savez(os.path.join(args.out, f"scene_{seed}.npz"), iq=iq[c // 3:c // 3 + 1], kw=kw)
                     break
+        if args.halfframes and not args.chunks:
+            r = np.random.default_rng(seed * 19 + 1)
+            ch = int(r.integers(0, iq.shape[0]))
+            mode = int(r.integers(0, 2))
+            b = lt.Batch(1, max(iq.shape[1], 9600), **kw)
+            b.set_mode(mode)
+            b.enable_halfframes(b.rec_cap)
+            b.run_host(iq[ch:ch + 1])
+            b.collect()
+            for root in range(3):
+                recs_o, hfs = O.chain_run(iq[ch], root, want_halfframes=True, **kw)
+                ghf = b.halfframes(root)
+                n_variants += 1
+                if ghf.shape != hfs.shape or not np.array_equal(ghf.view(np.uint32), hfs.view(np.uint32)):
+                    bad.append({"seed": seed, "mode": mode, "channel": ch, "root": root, "kw": kw,
+                                "what": f"half-frames differ from the oracle's ({ghf.shape} vs {hfs.shape})"})
+                    print(json.dumps(bad[-1]), file=sys.stderr, flush=True)
+                    break
+            b.close()
         if args.overlap_runs and not args.chunks:
             import torch
             dev = torch.device("cuda", 0)
