@@ -122,44 +122,52 @@ def rate_match_pattern(D=40):
     return np.array(out)
 
 
+_VIT = None
+
+
+def _viterbi_tables():
+    """Trellis of the (133,171,165) code: for every next state its two predecessors (even one first), the input bit
+    that leads there and the sign (+1: coded bit 0) of the three coded bits on each of the two branches."""
+    global _VIT
+    if _VIT is None:
+        polys = [0o133, 0o171, 0o165]
+        ns = np.arange(64)
+        b = ns >> 5                      # input bit: the shift register's newest entry
+        s0 = (ns & 31) << 1              # predecessors s0, s0 + 1: next = (s >> 1) | (b << 5)
+        sign = np.zeros((2, 64, 3))
+        for j in range(2):
+            for n in range(64):
+                reg = (int(b[n]) << 6) | (int(s0[n]) + j)
+                for i, p in enumerate(polys):
+                    sign[j, n, i] = 1.0 - 2.0 * (bin(reg & p).count("1") & 1)
+        _VIT = (s0, b.astype(np.int8), sign)
+    return _VIT
+
+
 def viterbi_tailbiting(llr, nbits=40):
     """Rate-1/3 K=7 (133,171,165) tail-biting Viterbi on soft bits (positive = 0); llr is
-    [nbits, 3].  Three passes over the circular trellis, decisions taken from the middle pass."""
-    polys = [0o133, 0o171, 0o165]
-    nstates = 64
-    # output bits for (state, input): shift register holds the 6 previous inputs, newest at the MSB
-    outs = np.zeros((nstates, 2, 3), np.int8)
-    for s in range(nstates):
-        for b in range(2):
-            reg = (b << 6) | s
-            for i, p in enumerate(polys):
-                outs[s, b, i] = bin(reg & p).count("1") & 1
-    nxt = np.zeros((nstates, 2), np.int64)
-    for s in range(nstates):
-        for b in range(2):
-            nxt[s, b] = (s >> 1) | (b << 5)
+    [nbits, 3].  Three passes over the circular trellis, decisions taken from the middle pass.
+    All 64 states of a step at once; a state reached with equal metrics from both predecessors keeps the even one
+    (the first a state-by-state loop with a strict comparison would meet)."""
+    s0, bit, sign = _viterbi_tables()
     passes = 3
     T = nbits * passes
-    metric = np.zeros(nstates)
-    back = np.zeros((T, nstates), np.int8)
-    prev = np.zeros((T, nstates), np.int64)
+    metric = np.zeros(64)
+    prev = np.zeros((T, 64), np.int64)
+    llr = np.asarray(llr, dtype=np.float64)
     for t in range(T):
         l = llr[t % nbits]
-        new = np.full(nstates, -np.inf)
-        for s in range(nstates):
-            for b in range(2):
-                o = outs[s, b]
-                m = metric[s] + np.sum(np.where(o == 0, l, -l))
-                ns_ = nxt[s, b]
-                if m > new[ns_]:
-                    new[ns_] = m
-                    back[t, ns_] = b
-                    prev[t, ns_] = s
+        bm = (sign[:, :, 0] * l[0] + sign[:, :, 1] * l[1]) + sign[:, :, 2] * l[2]  # branch metrics, summed in order
+        m0 = metric[s0] + bm[0]
+        m1 = metric[s0 + 1] + bm[1]
+        odd = m1 > m0
+        new = np.where(odd, m1, m0)
+        prev[t] = s0 + odd
         metric = new - new.max()
     s = int(np.argmax(metric))
     bits = np.zeros(T, np.uint8)
     for t in range(T - 1, -1, -1):
-        bits[t] = back[t, s]
+        bits[t] = bit[s]
         s = prev[t, s]
     return bits[nbits:2 * nbits]
 

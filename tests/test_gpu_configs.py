@@ -5,8 +5,10 @@ config 2: one 50-PRB channel at 15.36 Msps through the device decimator (x8) and
 config 5: the 100-PRB fixture at 30.72 Msps plus AWGN, decimated x16 on the device, threshold 4.  SNR as in
           examples/snr_ltetrigger.grc:612-663: mean signal power over mean noise power across the full sampled
           band, both taken before the sum.  Three SNR points across the knee of the detection curve
-          (profiles/r01_configs_1_2_5.json: 0 % at -8 dB, 100 % at 0 dB), seeded trials: the GPU path has to
-          detect in exactly the trials in which the CPU oracle does, with every record field on the parity bar.
+          (profiles/r03_configs_1_2_5.json: 0 % at -6 dB, 64 % at -4 dB, 100 % at -2 dB), seeded trials: the GPU path
+          has to detect in exactly the trials in which the CPU oracle does, with every record field on the parity bar.
+          The knee point itself (-4 dB) runs at the config's full length, 1 s per trial; the two beside it 0.25 s.
+          (The whole curve -- -10..+10 dB, 50 trials, 1 s -- is bench.py's `config5` leg.)
 """
 import numpy as np
 import pytest
@@ -62,13 +64,11 @@ def test_config5_snr_sweep_detection_equals_oracle(lt, oracle):
     dev = torch.device("cuda", 0)
     raw, decim, _ = load_frame("100prb")
     assert decim == 16
-    frames = 25  # 0.25 s per trial: a 20 dB cell is published after ~0.1 s
-    sig = torch.from_numpy(np.tile(raw, frames)).to(dev)
+    frames_of = {-6: 25, -4: 100, -2: 25}  # 0.25 s per trial (a 20 dB cell is published after ~0.1 s); the knee point 1 s
+    sig_full = torch.from_numpy(np.tile(raw, max(frames_of.values()))).to(dev)
     p_sig = float(np.mean(np.abs(raw) ** 2))  # over the full 30.72 MHz band
-    n_in, n_out = sig.numel(), sig.numel() // 16
     dec = lt.Decim(16)
     trials = 10
-    bt = lt.BatchTrigger(trials, n_out, psr_threshold=4.0, exit_on_success=True)
     s = torch.cuda.current_stream(dev)
     rates = {}
     # One noise realisation per trial, drawn on the host (numpy's generator gives the same samples on every box; the
@@ -77,12 +77,15 @@ def test_config5_snr_sweep_detection_equals_oracle(lt, oracle):
     noises = []
     for t in range(trials):
         rng = np.random.default_rng(500000 + t)
-        nz = rng.standard_normal((n_in, 2), dtype=np.float32)
+        nz = rng.standard_normal((sig_full.numel(), 2), dtype=np.float32)
         noises.append(torch.view_as_complex(torch.from_numpy(nz).to(dev)))
     for snr in (-6, -4, -2):
+        sig = sig_full[:raw.size * frames_of[snr]]
+        n_in, n_out = sig.numel(), sig.numel() // 16
+        bt = lt.BatchTrigger(trials, n_out, psr_threshold=4.0, exit_on_success=True)
         y = torch.empty((trials, n_out), dtype=torch.complex64, device=dev)
         for t in range(trials):
-            xin = sig + noises[t] * float(np.sqrt(p_sig / (10.0 ** (snr / 10.0)) / 2.0))
+            xin = sig + noises[t][:n_in] * float(np.sqrt(p_sig / (10.0 ** (snr / 10.0)) / 2.0))
             dec.run_device(torch.view_as_real(xin).data_ptr(), torch.view_as_real(y[t]).data_ptr(), 1, n_in, s.cuda_stream)
         torch.cuda.synchronize()
         recs, events = bt.process_device(y)
@@ -100,6 +103,7 @@ def test_config5_snr_sweep_detection_equals_oracle(lt, oracle):
                 assert (g["cell_id"], g["nof_prb"], g["nof_tx_ports"]) == (oc["cell_id"], oc["nof_prb"], oc["nof_tx_ports"])
             det.append(bool(g and g["cell_id"] == 369 and g["nof_prb"] == 100))
         rates[snr] = sum(det) / trials
-    # the knee: detection does not get worse with SNR, and the top point detects (mostly)
-    assert rates[-6] <= rates[-4] + 0.2 and rates[-4] <= rates[-2] + 0.2, rates
-    assert rates[-2] >= 0.5, rates
+    # the knee: detection does not get worse with SNR (between the two points of one length; the knee point has four times
+    # the time to find its cell), and the top point detects (mostly)
+    assert rates[-6] <= rates[-2] + 0.2 and rates[-6] <= rates[-4] + 0.2, rates
+    assert rates[-2] >= 0.5 and rates[-4] >= 0.3, rates
