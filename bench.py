@@ -6,7 +6,7 @@ each rank owns 64 independent 1.92 Msps capture channels of 1 s each, built from
 bundled fixtures (decimated to 1.92 Msps, seeded rotation, looped, AWGN 20 dB, every 8th
 channel noise only), resident in HBM before the timed region.  One step = one pass of the
 PSS->SSS path over the whole batch (state reset + grid scan + per-chain kernel + per-record kernels).
-Channels are independent, so ranks never exchange data; torch.distributed is used for the barrier and the
+Channels are independent, so ranks never exchange data; torch.distributed (gloo, on host tensors: no RCCL) is used for the barrier and the
 max-over-ranks of the wall time only.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
@@ -33,6 +33,7 @@ FS = 1_920_000
 FIXTURES = [("lte_frame_6prb_cellid_123", 1, 123), ("lte_frame_25prb_cellid_124", 4, 124),
             ("lte_frame_50prb_cellid_125", 8, 125), ("lte_frame_100prb_cellid_369", 16, 369)]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 ALGO_BYTES_PER_SAMPLE = 8.0  # cf32 read exactly once, all three roots + SSS served from it
 STAGES = ("grid_scan", None, "lt_chain_kernel", "per_record")  # lt_batch_phase_ms slots
 # kernels rocprofv3 sees per stage (profiles/traffic.json is keyed by kernel name)
@@ -211,10 +212,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the hot path)")
+    # (a rehearsal of the N > 1 path on a box with fewer GPUs than ranks maps the ranks onto the GPUs there are, and the
+    # line says so: `ranks_per_gpu`; on the node the driver uses there is one GPU per rank)
+    n_dev = torch.cuda.device_count()
+    ranks_per_gpu = (world + n_dev - 1) // n_dev
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # north_star: no RCCL -- the ranks never exchange data.  The barrier and the two scalar reductions of the report run
+        # over gloo on host tensors.
+        dist.init_process_group("gloo")
+    cpu = torch.device("cpu")
 
     n_ch = args.channels
     n = int(round(args.seconds * FS))
@@ -270,7 +279,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timed_region_ms = ev_t0.elapsed_time(ev_t1) / max(args.steps, 1)
 
-    elapsed = sharding.max_over_ranks(dist, torch, elapsed, dev)
+    elapsed = sharding.max_over_ranks(dist, torch, elapsed, cpu)
     if args.steps <= 0:
         if rank == 0:
             print(json.dumps({"metric": "IQ Msamp/s through PSS+SSS detect", "value": None, "unit": "Msamp/s",
@@ -312,7 +321,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        dt_st = sharding.max_over_ranks(dist, torch, time.perf_counter() - t2, dev)
+        dt_st = sharding.max_over_ranks(dist, torch, time.perf_counter() - t2, cpu)
         recs_st = batch.collect()
         v_st = sharding.aggregate_msamp_per_s(world, n_ch, n, 50, dt_st)
         steady_leg = {"value": round(v_st, 3), "unit": "Msamp/s", "steps": 50, "ms_per_step": round(dt_st / 50 * 1e3, 4),
@@ -340,7 +349,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        dt_ov = sharding.max_over_ranks(dist, torch, time.perf_counter() - t1, dev)
+        dt_ov = sharding.max_over_ranks(dist, torch, time.perf_counter() - t1, cpu)
         recs_ov = batch.collect()
         same_ov = all(a.tobytes() == b_.tobytes() for a, b_ in zip(recs, recs_ov))
         batch.set_overlap(False)
@@ -353,9 +362,25 @@ def main():
     found = cells_found(lt, recs, n_ch)
     ok = sum(1 for c in range(n_ch)
              if found[c] == (set() if expect[c] < 0 else {int(expect[c])}))
-    ok_sum, ch_sum = sharding.sum_over_ranks(dist, torch, [ok, n_ch], dev)
+    ok_sum, ch_sum = sharding.sum_over_ranks(dist, torch, [ok, n_ch], cpu)
     match_rate = ok_sum / ch_sum
 
+    # End to end (pinned host -> H2D -> kernels -> records back): at N > 1 every rank feeds its GPU at the same time, behind a
+    # barrier -- the host side of the feed (memory bandwidth, PCIe root complexes) is the one thing the ranks share, and the
+    # only thing that can bend the scaling curve of a path without collectives.
+    e2e = None
+    if not args.no_end_to_end:
+        if world > 1:
+            dist.barrier()
+        e2e = end_to_end(torch, lt, iq, n_ch, n, local_rank)
+        if world > 1:
+            dt_max = sharding.max_over_ranks(dist, torch, e2e["seconds"], cpu)
+            h2d_min = sharding.min_over_ranks(dist, torch, e2e["h2d_gbs"], cpu)
+            h2d_sum, = sharding.sum_over_ranks(dist, torch, [e2e["h2d_gbs"]], cpu)
+            e2e = dict(e2e, value=round(world * n_ch * n * e2e["passes"] / dt_max / 1e6, 3), rank0_value=e2e["value"],
+                       h2d_gbs=round(h2d_sum, 2), h2d_gbs_min_rank=round(h2d_min, 2), h2d_gbs_rank0=e2e["h2d_gbs"],
+                       what=e2e["what"].replace("one GPU", f"{world} ranks at the same time: value = all ranks' samples / the "
+                                                "slowest rank's time, h2d_gbs = sum over ranks, h2d_gbs_min_rank = the slowest feed"))
     if rank == 0:
         value = sharding.aggregate_msamp_per_s(world, n_ch, n, args.steps, elapsed)
         algo_bytes = ALGO_BYTES_PER_SAMPLE * n_ch * n  # per launch and GPU
@@ -372,6 +397,16 @@ def main():
             "lt_chain_kernel": 0.0,
             "per_record": sss_ran * (128 + 480 + 128) * 8.0 + calls * 3 * 96.0,
         }
+        # The arithmetic: a root wave's window is 935 flop per lane (last forward stage, filter spectrum,
+        # inverse transform, |.|^2, average), a forward wave's block 450 (two transform stages): per searched window of a
+        # chain 12 strips x 64 lanes x 935, per distinct window of a channel (the chains on one alignment share the
+        # forward transform) 12 x 64 x 450.  Counted on what the records say was searched, not on what the rounds ran
+        # speculatively.
+        distinct = 0
+        for ch in range(n_ch):
+            pos = [recs[ch * 3 + r]["in_pos"][(recs[ch * 3 + r]["flags"] & lt.F_SEARCHED) != 0] for r in range(3)]
+            distinct += int(np.unique(np.concatenate(pos)).size)
+        flop_step = 12 * 64 * (935.0 * searched + 450.0 * distinct)
         traffic, traffic_src = load_traffic()
         kernels = []
         for name, ms in zip(STAGES, phase_ms):
@@ -409,7 +444,9 @@ def main():
                 "overlap": ("off" if not args.overlap else
                             "lt_batch_set_overlap(1): a step's per-record kernels (CFO, CP, SSS) run on a second stream beside "
                             "the next step's scan rounds; every step's records are complete inside the timed region"),
-                "sharding": "independent channels per rank, no collective on the data path",
+                "sharding": "independent channels per rank, no collective on the data path (barrier and scalar reductions of the "
+                            "report over gloo on host tensors: no RCCL)",
+                "ranks_per_gpu": ranks_per_gpu,
             },
             "cell_id_match_rate": match_rate,
             "window_cache": dict(zip(("windows_listed", "searches_cached", "searches_transformed", "chains_waiting", "moved_off_grid", "reruns_cached", "reruns_transformed"), cache_stats)),
@@ -423,6 +460,14 @@ def main():
             # lt_plan_kernel + lt_scan_kernel + lt_resolve_kernel launches).
             "roofline": {
                 "bound": "hbm",
+                "binds": "valu",
+                "bound_note": "reported against HBM as north_star asks (8 B per input sample); what binds the path is fp32 vector "
+                              "issue (a matched filter of ~250 flop per 8-byte sample even as an FFT): see `valu`",
+                "valu": {"flop_per_launch": flop_step, "achieved": round(flop_step / (elapsed / args.steps) / 1e12, 2),
+                         "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step / (elapsed / args.steps) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                         "searched_windows": searched, "distinct_windows": distinct,
+                         "note": "935 flop per lane and searched (chain, window, strip), 450 per distinct (channel, window, strip) "
+                                 "[DESIGN 4.6]; peak = 157.3 TFLOP/s fp32 vector, which counts every slot as a fused multiply-add"},
                 "kernel": "lt_scan_kernel (dominant; stage '%s' = %s)" % (dom["stage"], " + ".join(dom["kernels"])),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "achieved": round(algo_bytes / (elapsed / args.steps) / 1e9, 2),
@@ -449,8 +494,8 @@ def main():
         if steady_leg is not None:
             out["steady_state"] = steady_leg
         # the side measurements run at N = 1 only (rank 0 would keep the other ranks waiting at the last barrier)
-        if world == 1 and not args.no_end_to_end:
-            out["end_to_end"] = end_to_end(torch, lt, iq, n_ch, n, local_rank)
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if world == 1 and not args.no_config2:
             out["config2"] = config2(torch, lt, dev, local_rank)
         if world == 1 and not args.no_config5:
@@ -519,7 +564,7 @@ def end_to_end(torch, lt, iq, n_ch, n, device):
     dt = time.perf_counter() - t0
     for b in batches:
         b.close()
-    return {"value": round(n_ch * n * passes / dt / 1e6, 3), "unit": "Msamp/s", "passes": passes,
+    return {"value": round(n_ch * n * passes / dt / 1e6, 3), "unit": "Msamp/s", "passes": passes, "seconds": dt,
             "ms_per_pass": round(dt / passes * 1e3, 3),
             "h2d_gbs": round(n_ch * n * 8.0 * passes / dt / 1e9, 2),
             "what": "pinned host -> hipMemcpyAsync -> kernels -> records D2H, double-buffered over two streams; one GPU"}
@@ -778,6 +823,16 @@ def cpu_baseline(lt, iq, gpu_recs, n_ch, gpu_value_per_gpu, threads=0):
             ties += 1
         else:
             same = False
+    # all the host's cores: one pass with a thread per available core (3 x n_ch chains at most are
+    # busy: OpenMP deals chains to threads)
+    all_cores = None
+    if nproc_avail > cores:
+        t0 = time.perf_counter()
+        O.batch_run(x, nthreads=nproc_avail)
+        dta = time.perf_counter() - t0
+        all_cores = {"value": round(x.size / dta / 1e6, 3), "unit": "Msamp/s", "threads": nproc_avail,
+                     "busy_at_most": min(nproc_avail, 3 * n_ch),
+                     "sample": f"the same {n_ch} channels, one pass ({dta:.2f} s), OpenMP over the {3 * n_ch} chains"}
     # single core: a smaller sample of the same batch, one thread
     n1 = min(n_ch, 8)
     t0 = time.perf_counter()
@@ -795,6 +850,7 @@ def cpu_baseline(lt, iq, gpu_recs, n_ch, gpu_value_per_gpu, threads=0):
                   f"~{dt * cores * passes + dt1:.0f} core-seconds in total)",
         "single_core": {"value": round(x[:n1].size / dt1 / 1e6, 3), "unit": "Msamp/s",
                         "sample": f"first {n1} channels, one thread, one pass ({dt1:.2f} s)"},
+        "all_cores": all_cores,
         "arg_max_ties": ties,
         "nproc": nproc,
         "nproc_available": nproc_avail,

@@ -350,7 +350,10 @@ class Batch:
         _check(lib().lt_batch_set_window_cache(self._h, int(level)), "lt_batch_set_window_cache")
 
     def cache_stats(self):
-        """(windows asked for, cached searches, uncached searches of pass 1, chains that waited, hits that moved one off its grid)."""
+        """lt_batch_cache_stats of the last run, 7 values: (windows asked for, searches of pass 1 served from the cache,
+        searches of pass 1 through the transforms, chains that waited for the cache, hits that moved such a chain off the
+        grid its windows were listed on, windows an average was run through again from the cache, the same through the
+        transforms)."""
         v = np.zeros(7, np.int64)
         _check(lib().lt_batch_cache_stats(self._h, v.ctypes.data_as(C.c_void_p)), "lt_batch_cache_stats")
         return tuple(int(x) for x in v)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -106,7 +107,7 @@ struct lt_pss {
   lt_cf32 *d_win = nullptr;
   FindResultHost *d_res = nullptr;
   float *d_cfo = nullptr;
-  float peak_value = 0.f;
+  std::atomic<float> peak_value{0.f}; // (read by lt_pss_get_peak_value from any thread)
 };
 
 struct lt_cfo {
@@ -121,9 +122,10 @@ struct lt_cfo {
 struct lt_sync {
   int device = 0;
   int n_id_2 = 10;
-  int cp = LT_CP_NORM;
-  int cp_len = 9;
-  int n_id_1 = 1000; // invalid
+  // (the three below are read by the plain getters from any thread while the handle is busy on its own)
+  std::atomic<int> cp{LT_CP_NORM};
+  std::atomic<int> cp_len{9};
+  std::atomic<int> n_id_1{1000}; // invalid
   hipStream_t stream = nullptr;
   const lt::DeviceTables *tab = nullptr;
   lt_cf32 *d_in = nullptr;
@@ -198,6 +200,7 @@ struct lt_decim {
   int decimation = 1;
   std::vector<float> taps;
   float *d_taps = nullptr;
+  float *d_tap_table = nullptr; // the taps in the order lt_decim_kernel<D, NTAPS> walks them (the reference's rates)
   hipStream_t stream = nullptr;
   lt_cf32 *d_x = nullptr, *d_y = nullptr;
   size_t x_cap = 0, y_cap = 0;
@@ -446,7 +449,7 @@ int lt_sync_set_cp(lt_sync *q, int cp)
   return LT_OK;
 }
 
-int lt_sync_get_cp_len(lt_sync *q) { return q ? q->cp_len : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
+int lt_sync_get_cp_len(lt_sync *q) { return q ? q->cp_len.load(std::memory_order_relaxed) : fail(LT_ERROR_INVALID_INPUTS, "null handle"); }
 
 int lt_sync_get_cp_metrics(lt_sync *q, float *n, float *e)
 {
@@ -502,8 +505,9 @@ int lt_sss_N_id_1(lt_sync *q, uint32_t m0, uint32_t m1)
 int lt_sync_get_cell_id(lt_sync *q)
 {
   if (!q) return fail(LT_ERROR_INVALID_INPUTS, "null handle");
-  if (q->n_id_2 < 0 || q->n_id_2 > 2 || q->n_id_1 < 0 || q->n_id_1 > 167) return -1;
-  return q->n_id_1 * 3 + q->n_id_2;
+  const int n_id_1 = q->n_id_1.load(std::memory_order_relaxed);
+  if (q->n_id_2 < 0 || q->n_id_2 > 2 || n_id_1 < 0 || n_id_1 > 167) return -1;
+  return n_id_1 * 3 + q->n_id_2;
 }
 
 // ------------------------------------------------------------------ batch
@@ -762,6 +766,14 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
     HIP_TRY(hipEventRecord(b->rec_done[set], b->side));
     b->rec_done_valid[set] = true;
     b->side_busy = true;
+  } else if (b->overlap && b->rec_done[set]) {
+    // A run that is not overlapped itself (host buffer, lt_batch_push) between overlapped ones: its records are complete
+    // when its stream is through -- the event says so to lt_batch_collect_previous (and to the overlapped run two runs on
+    // that writes this set again), which would otherwise wait on whatever an older run left in rec_done[set].
+    HIP_TRY(hipEventRecord(b->rec_done[set], s));
+    b->rec_done_valid[set] = true;
+  } else {
+    b->rec_done_valid[set] = false;
   }
   b->cur_recs = R.recs;
   b->cur_count = R.rec_count;
@@ -851,9 +863,9 @@ int lt_batch_collect_previous(lt_batch *b, lt_record *recs, int64_t cap_per_chai
   if (b->n_runs < 2) return fail(LT_ERROR, "lt_batch_collect_previous: fewer than two runs so far");
   // the run before the last one wrote the other set if and only if both were overlapped runs
   const int set = b->cur_recs == b->d_recs ? 1 : 0;
-  if (!b->d_recs_b || b->set_run[set] != b->n_runs - 1)
+  if (!b->d_recs_b || b->set_run[set] != b->n_runs - 1 || !b->rec_done_valid[set])
     return fail(LT_ERROR, "lt_batch_collect_previous: the last run has overwritten the records of the one before "
-                          "(two sets of records exist only between overlapped runs, lt_batch_set_overlap)");
+                          "(two sets of records exist only while lt_batch_set_overlap is on and the last run was an overlapped one)");
   HIP_TRY(hipSetDevice(b->device));
   if (!b->copy) HIP_TRY(hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
   // that run's per-record kernels are through when its event is (the last run's may still be under way)
@@ -1005,6 +1017,11 @@ int lt_decim_create(lt_decim **out, int device, int decimation)
   hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&d->d_taps, sizeof(float) * d->taps.size());
   if (e == hipSuccess) e = hipMemcpy(d->d_taps, d->taps.data(), sizeof(float) * d->taps.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && lt::decim_has_tap_table(decimation, (int)d->taps.size())) {
+    const std::vector<float> tt = lt::decim_tap_table(decimation, d->taps.data(), (int)d->taps.size());
+    e = hipMalloc(&d->d_tap_table, sizeof(float) * tt.size());
+    if (e == hipSuccess) e = hipMemcpy(d->d_tap_table, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     lt_decim_free(d);
     return fail(LT_ERROR, "lt_decim_create: %s", hipGetErrorString(e));
@@ -1018,6 +1035,7 @@ void lt_decim_free(lt_decim *d)
   if (!d) return;
   (void)hipSetDevice(d->device);
   if (d->d_taps) (void)hipFree(d->d_taps);
+  if (d->d_tap_table) (void)hipFree(d->d_tap_table);
   if (d->d_x) (void)hipFree(d->d_x);
   if (d->d_y) (void)hipFree(d->d_y);
   if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -1041,7 +1059,7 @@ int lt_decim_run(lt_decim *d, const lt_cf32 *x, lt_cf32 *y, int n_channels, int6
   const int64_t n_out = n_in / d->decimation;
   if (on_device) {
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : d->stream;
-    HIP_TRY(lt::launch_decim(x, y, n_channels, n_in, d->decimation, d->d_taps, (int)d->taps.size(), s));
+    HIP_TRY(lt::launch_decim(x, y, n_channels, n_in, d->decimation, d->d_taps, (int)d->taps.size(), d->d_tap_table, s));
     return LT_OK;
   }
   const size_t xb = sizeof(lt_cf32) * (size_t)n_channels * (size_t)n_in;
@@ -1059,7 +1077,7 @@ int lt_decim_run(lt_decim *d, const lt_cf32 *x, lt_cf32 *y, int n_channels, int6
     d->y_cap = yb;
   }
   if (xb) HIP_TRY(hipMemcpyAsync(d->d_x, x, xb, hipMemcpyHostToDevice, d->stream));
-  HIP_TRY(lt::launch_decim(d->d_x, d->d_y, n_channels, n_in, d->decimation, d->d_taps, (int)d->taps.size(), d->stream));
+  HIP_TRY(lt::launch_decim(d->d_x, d->d_y, n_channels, n_in, d->decimation, d->d_taps, (int)d->taps.size(), d->d_tap_table, d->stream));
   if (yb) HIP_TRY(hipMemcpyAsync(y, d->d_y, yb, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   return LT_OK;

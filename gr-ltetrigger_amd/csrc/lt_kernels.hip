@@ -103,85 +103,158 @@ __global__ __launch_bounds__(128) void lt_sss_m0m1_kernel(const v2f *__restrict_
 }
 
 // ---------------------------------------------------------------- decimating FIR
-// y[c][k] = sum_j taps[j] * x[c][k*D - j].  One thread per output sample; a block stages the
-// (64*D + ntaps) input samples it needs in LDS with coalesced loads.
-constexpr int kDecimThreads = 256;
-constexpr int kDecimOutPerThread = 2;
-constexpr int kDecimOutPerBlock = kDecimThreads * kDecimOutPerThread;
+// y[c][k] = sum_j taps[j] * x[c][k*D - j], accumulated in tap order as a chain of fused multiply-adds (the oracle's
+// order, oracle/lte_oracle.c orc_decimate: one rounding per tap).
+//
+// lt_decim_kernel<D, NTAPS> (the reference's rates, D = 4 / 8 / 16 with GNU Radio's default 131 / 263 / 525 taps): a thread
+// owns B = 32 / D ADJACENT outputs, so that one sample read serves B taps -- sample i is tap j of output k and tap j + D of
+// output k + 1 --: per step s one 8-byte LDS read and B packed FMAs, acc[b] += taps[s + b D] * X_s, where X_s is
+// the sample D B l + const - s for lane l.  Every accumulator sees its taps in ascending order.  The block's input span is
+// staged in LDS phase by phase, 32 phases (sample u at row u mod 32, column u / 32): for a given step all lanes of a
+// wave read one row at consecutive columns (conflict-free 8-byte reads), and the staging stores of a 16-lane group go to
+// 16 rows that start on distinct even banks (row length 273 = 1 mod 16).  32 phases x 256 threads x 8 B = 70 KB: two
+// blocks per CU, one staging its samples while the other computes.  The taps are wave-uniform: scalar loads, 32 at a time
+// from a table laid out in the order the steps use them (decim_tap_table).
+// Algorithmic bytes: 8 B in + 8/D B out per input sample; arithmetic: 2 NTAPS / D FMAs per input sample.
+//
+// lt_decim_generic_kernel: any other rate, one thread per output, same arithmetic.
+constexpr int kDecimThreads = 256; // (128 and 512 measured: 3 % and 15 % slower)
+constexpr int kDecimPhases = 32;
+constexpr int kDecimRow = kDecimThreads + 17; // row length in samples: >= threads + lead / 32, = 1 mod 16
 
-// Row length (in samples) of the polyphase staging area: >= cols, and such that the D rows a 16-lane
-// group of the staging store touches start on distinct even banks (R = 16/D mod 32 for D | 16, else odd).
-__host__ __device__ inline int decim_row_len(int cols, int D)
+__host__ __device__ constexpr int decim_lead(int ntaps) { return ((ntaps - 1 + kDecimPhases - 1) / kDecimPhases) * kDecimPhases; }
+
+__device__ __forceinline__ v2f fma_tap(float t, v2f x, v2f acc)
 {
-  const int want = (D <= 16 && (16 % D) == 0) ? 16 / D : 1;
-  int R = cols;
-  while ((R & 31) != (want & 31)) ++R;
-  return R;
+  const v2f tt = {t, t};
+  return __builtin_elementwise_fma(tt, x, acc);
 }
 
-// y[c][k] = sum_j taps[j] x[c][k D - j], accumulated in tap order with an unfused multiply-add (the
-// oracle's and GNU Radio's generic kernel order).  The block's input span is staged in LDS phase by
-// phase (sample i at row i mod D, column i / D): for a given tap all lanes then read one row at
-// consecutive columns -- conflict-free, where the natural layout would put every D-th sample of a wave
-// on the same banks.  Two outputs per thread run as independent add chains.
-// kD = decimation known at compile time (4, 8, 16: the reference's rates), or 0: read it from the argument.
-template <int kD>
+template <int kD, int kNtaps>
 __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
-                                                                 int64_t n_in, int64_t n_out, int D_arg,
-                                                                 const float *__restrict__ taps, int ntaps, int R)
+                                                                    int64_t n_in, int64_t n_out, const float *__restrict__ tt)
 {
-  extern __shared__ v2f xs[]; // D rows of R samples
-  const int D = kD ? kD : D_arg;
-  const int c = blockIdx.y, tid = threadIdx.x;
-  const int64_t k0 = (int64_t)blockIdx.x * kDecimOutPerBlock;
-  const v2f *xc = x + (int64_t)c * n_in;
-  // oldest input sample needed, moved down to a multiple of D so that sample `first + i` has phase i mod D
-  const int lead = ((ntaps - 1 + D - 1) / D) * D; // >= ntaps - 1
-  const int64_t first = k0 * D - lead;
-  const int span = kDecimOutPerBlock * D + lead;
-  for (int i = tid; i < span; i += kDecimThreads) xs[(i % D) * R + i / D] = ld_clip(xc, n_in, first + i);
-  __syncthreads();
-  // newest sample of output k0 + o sits at i = lead + o D: row 0, column lead / D + o
-  float re[kDecimOutPerThread], im[kDecimOutPerThread];
+  constexpr int P = kDecimPhases, B = P / kD, T = kDecimThreads, R = kDecimRow;
+  static_assert(P % kD == 0 && B >= 1, "the decimation must divide the 32 phases");
+  constexpr int lead = decim_lead(kNtaps);
+  constexpr int span = P * T + lead;
+  static_assert(T + lead / P <= R, "row too short");
+  constexpr int n_steps = kNtaps + (B - 1) * kD; // s = -(B - 1) D .. NTAPS - 1
+  constexpr int W0 = lead + P - kD; // u = 32 tid + W0 - n for step n
+  __shared__ v2f xs[P * R];
+  const int tid = threadIdx.x, c = blockIdx.y;
+  const int64_t k0 = (int64_t)blockIdx.x * (T * B);
+  const int64_t first = k0 * kD - lead; // input sample of u = 0
+  // ---- stage the span: the channel's samples [first, first + span) as a buffer resource (what lies outside the channel
+  // -- in front of the stream, behind its end -- is out of range and reads as zero)
+  {
+    const int64_t base_i = first > 0 ? first : 0;
+    int64_t avail = n_in - base_i;
+    avail = avail < 0 ? 0 : avail > span ? span : avail;
+    const v2f *bp = x + (int64_t)c * n_in + base_i;
+    const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(bp), 0, (int)avail * (int)sizeof(v2f), 0x00020000);
+    const int shift = (int)(first - base_i); // <= 0: offsets of samples in front of the stream wrap to huge unsigned values
+    const int row = tid & (P - 1), col0 = tid >> 5;
+    v2f *dst = xs + row * R + col0;
+    constexpr int n_it = (span + T - 1) / T;
+    constexpr int kBatch = n_it; // all of a thread's loads in flight together: one memory round trip per block
 #pragma unroll
-  for (int o = 0; o < kDecimOutPerThread; ++o) re[o] = im[o] = 0.f;
-  const v2f *base = xs + lead / D + tid;
-  // tap j = q D + r reads sample i = lead + o D - j: row (-j) mod D = (D - r) mod D, column lead / D + o - q - (r > 0)
-  auto tap = [&](int j, const v2f *p) { // same order and rounding as the oracle: product, then add
-    const float t = taps[j];
+    for (int i0 = 0; i0 < n_it; i0 += kBatch) {
+      v2f v[kBatch];
 #pragma unroll
-    for (int o = 0; o < kDecimOutPerThread; ++o) {
-      const v2f v = p[o * kDecimThreads];
-      re[o] = __fadd_rn(re[o], __fmul_rn(t, v.x));
-      im[o] = __fadd_rn(im[o], __fmul_rn(t, v.y));
-    }
-  };
-  if (kD) {
-    const int nq = ntaps / kD; // whole groups of D taps
-    for (int q = 0; q < nq; ++q) {
-      const v2f *pq = base - q;
-#pragma unroll
-      for (int r = 0; r < kD; ++r) tap(q * kD + r, pq + ((kD - r) % kD) * R - (r > 0));
-    }
-    const v2f *pq = base - nq;
-#pragma unroll
-    for (int r = 0; r < kD; ++r)
-      if (nq * kD + r < ntaps) tap(nq * kD + r, pq + ((kD - r) % kD) * R - (r > 0));
-  } else {
-    int row = 0, col = 0;
-    for (int j = 0; j < ntaps; ++j) {
-      tap(j, base + row * R + col);
-      if (--row < 0) {
-        row += D;
-        --col;
+      for (int i = 0; i < kBatch; ++i) {
+        const int u = tid + (i0 + i) * T;
+        if (i0 + i < n_it) v[i] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(win, (shift + u) * (int)sizeof(v2f), 0, 0));
       }
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i)
+        if (i0 + i < n_it && (tid + (i0 + i) * T < span)) dst[(i0 + i) * (T / P)] = v[i];
     }
   }
+  __syncthreads();
+  v2f acc[B];
 #pragma unroll
-  for (int o = 0; o < kDecimOutPerThread; ++o) {
-    const int64_t k = k0 + tid + o * kDecimThreads;
-    if (k < n_out) y[(int64_t)c * n_out + k] = v2f{re[o], im[o]};
+  for (int b = 0; b < B; ++b) acc[b] = v2f{0.f, 0.f};
+  const v2f *xl = xs + tid;
+  // Step n (= s + (B - 1) D) reads sample u = 32 tid + W0 - n: row (W0 - n) mod 32, column tid + (W0 - n) / 32; output b
+  // takes it with tap j = n + (b - (B - 1)) D.  The steps run in units of U = D (32 taps each: two scalar loads of 16
+  // from the table `tt`, laid out [unit][step][output] by decim_tap_table below); a unit's LDS reads and taps are fetched
+  // while the unit before it computes.  Everything is unrolled: which (step, output) pairs have a tap is known here.
+  constexpr int U = kD, G = P / U; // G units per chunk of 32 steps (G = B: even, so a unit's buffer is its index's parity)
+  static_assert(U * B == 32 && G % 2 == 0, "a unit is 32 taps; the two buffers alternate in step with the chunks");
+  constexpr int m_last = (n_steps - 1) / P; // chunks 0 and m_last have (step, output) pairs without a tap: unrolled apart
+  static_assert(m_last >= 2 && P * (m_last - 1) + P - 1 <= kNtaps - 1 && P * 1 - (B - 1) * kD >= 0, "the steady chunks must lie inside the taps");
+  v2f xv[2][U];
+  float tv[2][32];
+  // unit g of chunk m: steps n = 32 m + g U + u
+#define LT_DECIM_LOAD(m, g, kPeel)                                                                       \
+  {                                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                        \
+    {                                                                                                    \
+      const int r = (g) * U + u;                                                                         \
+      if (!kPeel || P * (m) + r < n_steps) xv[(g) & 1][u] = xl[((W0 - r) & (P - 1)) * R + ((W0 - r) >> 5) - (m)]; \
+    }                                                                                                    \
+    const float *tp = tt + ((m) * G + (g)) * 32;                                                         \
+    _Pragma("unroll") for (int i = 0; i < 32; ++i) tv[(g) & 1][i] = tp[i];                               \
   }
+#define LT_DECIM_FMA(m, g, kPeel)                                                                        \
+  {                                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                        \
+    {                                                                                                    \
+      const int n = P * (m) + (g) * U + u;                                                               \
+      _Pragma("unroll") for (int b = 0; b < B; ++b)                                                      \
+      {                                                                                                  \
+        const int j = n + (b - (B - 1)) * kD;                                                            \
+        if (!kPeel || (n < n_steps && j >= 0 && j < kNtaps)) acc[b] = fma_tap(tv[(g) & 1][u * B + b], xv[(g) & 1][u], acc[b]); \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+  // one chunk: while unit g computes, unit g + 1 (or the next chunk's first) is on its way
+#define LT_DECIM_CHUNK(m, kPeel, kMore)                                                                  \
+  {                                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                        \
+    {                                                                                                    \
+      if (g + 1 < G) LT_DECIM_LOAD(m, g + 1, kPeel)                                                      \
+      else if (kMore) LT_DECIM_LOAD((m) + 1, 0, ((m) + 1 == m_last))                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+      LT_DECIM_FMA(m, g, kPeel)                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }                                                                                                    \
+  }
+  LT_DECIM_LOAD(0, 0, true)
+  LT_DECIM_CHUNK(0, true, true)
+#pragma unroll 1
+  for (int m = 1; m < m_last; ++m) LT_DECIM_CHUNK(m, false, true)
+  LT_DECIM_CHUNK(m_last, true, false)
+#undef LT_DECIM_CHUNK
+#undef LT_DECIM_FMA
+#undef LT_DECIM_LOAD
+  const int64_t k = k0 + (int64_t)B * tid;
+  v2f *yo = y + (int64_t)c * n_out + k;
+  if (k + B <= n_out) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) yo[b] = acc[b];
+  } else {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      if (k + b < n_out) yo[b] = acc[b];
+  }
+}
+
+// any decimation: one thread per output, samples from global memory (the taps walk down the stream: a lane's reads
+// are consecutive and stay in its cache lines)
+__global__ __launch_bounds__(kDecimThreads) void lt_decim_generic_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
+                                                                         int64_t n_in, int64_t n_out, int D,
+                                                                         const float *__restrict__ taps, int ntaps)
+{
+  const int c = blockIdx.y;
+  const int64_t k = (int64_t)blockIdx.x * kDecimThreads + threadIdx.x;
+  if (k >= n_out) return;
+  const v2f *xc = x + (int64_t)c * n_in;
+  v2f acc = {0.f, 0.f};
+  const int64_t base = k * D;
+  for (int j = 0; j < ntaps; ++j) acc = fma_tap(taps[j], ld_clip(xc, n_in, base - j), acc);
+  y[(int64_t)c * n_out + k] = acc;
 }
 
 // ---------------------------------------------------------------- CP length of the tracked half-frames 
@@ -961,25 +1034,49 @@ hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2,
   return hipGetLastError();
 }
 
+// The taps in the order lt_decim_kernel<D, NTAPS> walks them: [unit q][step u < D][output b < 32 / D] = taps[j],
+// j = q D + u + (b - (B - 1)) D (0 where the pair has no tap: never used).
+std::vector<float> decim_tap_table(int D, const float *taps, int ntaps)
+{
+  const int B = kDecimPhases / D, n_steps = ntaps + (B - 1) * D, Q = (n_steps + D - 1) / D;
+  std::vector<float> t((size_t)Q * 32, 0.f);
+  for (int q = 0; q < Q; ++q)
+    for (int u = 0; u < D; ++u)
+      for (int b = 0; b < B; ++b) {
+        const int j = q * D + u + (b - (B - 1)) * D;
+        if (j >= 0 && j < ntaps) t[(size_t)q * 32 + u * B + b] = taps[j];
+      }
+  return t;
+}
+bool decim_has_tap_table(int D, int ntaps) { return (D == 4 && ntaps == 131) || (D == 8 && ntaps == 263) || (D == 16 && ntaps == 525); }
+
 hipError_t launch_decim(const void *x, void *y, int n_channels, int64_t n_in, int D, const float *taps,
-                        int ntaps, hipStream_t stream)
+                        int ntaps, const float *tap_table, hipStream_t stream)
 {
   const int64_t n_out = n_in / D;
   if (n_out <= 0) return hipSuccess;
-  const int lead = ((ntaps - 1 + D - 1) / D) * D;
-  const int R = decim_row_len((kDecimOutPerBlock * D + lead + D - 1) / D, D);
-  const size_t lds = sizeof(v2f) * (size_t)D * (size_t)R;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  void (*kern)(const v2f *, v2f *, int64_t, int64_t, int, const float *, int, int) =
-      D == 4 ? lt_decim_kernel<4> : D == 8 ? lt_decim_kernel<8> : D == 16 ? lt_decim_kernel<16> : lt_decim_kernel<0>;
-  if (lds > 64 * 1024) { // (decimation 16: 70 KB)
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+  const v2f *xi = reinterpret_cast<const v2f *>(x);
+  v2f *yo = reinterpret_cast<v2f *>(y);
+  const int B = (D == 4 || D == 8 || D == 16) ? kDecimPhases / D : 0;
+  if (B && tap_table && n_channels <= 65535) {
+    const int64_t per_block = (int64_t)kDecimThreads * B;
+    const dim3 grid((unsigned)((n_out + per_block - 1) / per_block), (unsigned)n_channels);
+    if (D == 4 && ntaps == 131) {
+      hipLaunchKernelGGL((lt_decim_kernel<4, 131>), grid, dim3(kDecimThreads), 0, stream, xi, yo, n_in, n_out, tap_table);
+      return hipGetLastError();
+    }
+    if (D == 8 && ntaps == 263) {
+      hipLaunchKernelGGL((lt_decim_kernel<8, 263>), grid, dim3(kDecimThreads), 0, stream, xi, yo, n_in, n_out, tap_table);
+      return hipGetLastError();
+    }
+    if (D == 16 && ntaps == 525) {
+      hipLaunchKernelGGL((lt_decim_kernel<16, 525>), grid, dim3(kDecimThreads), 0, stream, xi, yo, n_in, n_out, tap_table);
+      return hipGetLastError();
+    }
   }
-  dim3 grid((unsigned)((n_out + kDecimOutPerBlock - 1) / kDecimOutPerBlock), (unsigned)n_channels);
-  hipLaunchKernelGGL(kern, grid, dim3(kDecimThreads), lds, stream, reinterpret_cast<const v2f *>(x),
-                     reinterpret_cast<v2f *>(y), n_in, n_out, D, taps, ntaps, R);
+  if (n_channels > 65535) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((n_out + kDecimThreads - 1) / kDecimThreads), (unsigned)n_channels);
+  hipLaunchKernelGGL(lt_decim_generic_kernel, grid, dim3(kDecimThreads), 0, stream, xi, yo, n_in, n_out, D, taps, ntaps);
   return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // Host-visible launch interface of lt_kernels.hip (keeps device types out of the C-ABI layer).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -72,7 +73,9 @@ int scan_counter_ints();
 int per_record_scratch_bytes();
 int cache_slot_bytes();
 int cache_counter_index(); // d_njobs[this] = slots asked for; [+1] searches served from the cache, [+2] searches through the
-                           // transforms in pass 1, [+3] chains that waited for the cache, [+4] hits that moved a waiting chain off its grid
+                           // transforms in pass 1, [+3] chains that waited for the cache, [+4] hits that moved a waiting chain off its grid,
+                           // [+5] / [+6] windows an average was run through again, from the cache / through the transforms
+                           // (the 7 values of lt_batch_cache_stats, include/ltetrigger_hip.h)
 int cache_max_per_chain();
 size_t chain_state_bytes();
 size_t chain_state_avg_offset();
@@ -90,7 +93,10 @@ hipError_t launch_detect_cp(const void *in, int peak_pos, void *sync_state, int 
 // res: device struct {int m0, m1; float m0_value, m1_value;}
 hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2, void *res,
                            hipStream_t stream);
+// tap_table: device copy of decim_tap_table(D, taps, ntaps) for the rates that have one (decim_has_tap_table), else null
 hipError_t launch_decim(const void *x, void *y, int n_channels, int64_t n_in, int D, const float *taps,
-                        int ntaps, hipStream_t stream);
+                        int ntaps, const float *tap_table, hipStream_t stream);
+std::vector<float> decim_tap_table(int D, const float *taps, int ntaps);
+bool decim_has_tap_table(int D, int ntaps);
 
 } // namespace lt

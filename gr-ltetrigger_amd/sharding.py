@@ -2,7 +2,8 @@
 
 Rank r of `world` owns the global channels [r*per_rank, (r+1)*per_rank) (channel c ->
 GPU c // 64).  torch.distributed is used only to line the ranks up (barrier), to take the slowest
-rank's wall time and to sum the per-rank match counters."""
+rank's wall time and to sum the per-rank match counters -- over gloo on host tensors: the design has no
+collective on the data path and therefore no use for RCCL."""
 
 
 def channel_range(rank, world, per_rank):
@@ -19,6 +20,13 @@ def max_over_ranks(dist, torch, value, device):
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def min_over_ranks(dist, torch, value, device):
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return float(t.item())
 
 

@@ -18,7 +18,10 @@
  *    only); the library stages them to the device itself and returns synchronously.
  *  - every handle owns its device buffers and HIP stream; distinct handles may be used
  *    from distinct threads concurrently (GNU Radio runs one thread per block); one handle
- *    must not be used from two threads at once.
+ *    must not be used from two threads at once -- except for the plain getters
+ *    lt_pss_get_peak_value, lt_sync_get_cp_len and lt_sync_get_cell_id, which read host-side
+ *    fields and may be polled from another thread while the handle is busy (the reference's
+ *    getters are called cross-thread without a lock, lib/pss_impl.h:95-100).
  *  - there is NO CPU fallback: every compute entry point fails with LT_ERROR when no
  *    gfx950 device is usable.
  */
@@ -232,8 +235,9 @@ int lt_batch_push(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_sa
 int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts);
 /* With overlap on, the records of the run BEFORE the last one (the two sets of records take turns): waits for that
  * run's per-record kernels only and copies on a stream of its own, so that  run(k + 1); collect_previous() -> run k's
- * records  keeps a run in flight all the time and still hands every run's records out.  Fails when the run before
- * the last one was not an overlapped run (its records have been overwritten). */
+ * records  keeps a run in flight all the time and still hands every run's records out.  Fails (LT_ERROR) when the last
+ * run has overwritten the records of the one before: the last run was not an overlapped one (a host buffer, a
+ * lt_batch_push, overlap off), or overlap was off when the run before it was made. */
 int lt_batch_collect_previous(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts);
 /* Upper bound on records per chain and run for chunks of n_samples (a call consumes >= 8640 samples; a chunk
  * may also finish calls left over from the one before). */

@@ -751,7 +751,12 @@ void orc_decim_design(int decim, float *taps)
   free(w);
 }
 
-/* y[k] = sum_j taps[j] * x[k*decim - j], x[<0] = 0 (history ntaps-1 of zeros) */
+/* y[k] = sum_j taps[j] * x[k*decim - j], x[<0] = 0 (history ntaps-1 of zeros).
+ * The sum runs in tap order as a chain of fused multiply-adds, acc = fma(taps[j], x, acc) -- one rounding per tap.
+ * GNU Radio's fir_filter hands this sum to VOLK, whose kernel (and with it the association and the use of FMA) is
+ * chosen per machine: the reference's own rounding is not defined beyond "a dot product in float", no fixture pins
+ * a decimated sample, and the cell fields the fixtures do pin (tests/test_oracle_fixtures.py) do not depend on it.
+ * Tap order + FMA is what AVX2/FMA VOLK kernels and the GPU's v_fma / v_pk_fma both execute natively. */
 int64_t orc_decimate(const orc_cf *x, int64_t n, int decim, const float *taps, int ntaps,
                      orc_cf *y)
 {
@@ -762,8 +767,8 @@ int64_t orc_decimate(const orc_cf *x, int64_t n, int decim, const float *taps, i
     for (int j = 0; j < ntaps; j++) {
       const int64_t i = base - j;
       if (i < 0) break;
-      re += taps[j] * x[i].re;
-      im += taps[j] * x[i].im;
+      re = fmaf(taps[j], x[i].re, re);
+      im = fmaf(taps[j], x[i].im, im);
     }
     y[k] = cf(re, im);
   }

@@ -539,6 +539,23 @@ def test_overlap_gives_the_same_records(lt, oracle, frames_192):
     bt.run_device(torch.view_as_real(bufs[1]).data_ptr(), n, s.cuda_stream)
     with pytest.raises(RuntimeError):  # one set of records without overlap: the run before the last is gone
         bt.collect_previous()
+    # a run from host memory (never overlapped: it writes the first set of records on the launch stream) followed by an
+    # overlapped one that happens to use the other set: the host run's records are still there, and collect_previous
+    # waits for THAT run (an event on its stream), not for whatever an older run left behind
+    bt = lt.Batch(6, n)
+    bt.set_overlap(True)
+    bt.run_host(a)
+    bt.run_device(torch.view_as_real(bufs[1]).data_ptr(), n, s.cuda_stream)
+    prev = [r.copy() for r in bt.collect_previous()]
+    cur = bt.collect()
+    for c in range(18):
+        assert prev[c].tobytes() == ref[0][c].tobytes(), f"chain {c} (host run, collected one run behind)"
+        assert cur[c].tobytes() == ref[1][c].tobytes(), f"chain {c} (the overlapped run after a host run)"
+    # ... and two host runs in a row share one set: the first one's records are gone, and the call says so
+    bt.run_host(a)
+    bt.run_host(b2)
+    with pytest.raises(RuntimeError):
+        bt.collect_previous()
     # and the first run is the oracle's
     want = oracle.batch_run(a, nthreads=8)
     for c in range(18):
