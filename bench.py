@@ -39,7 +39,7 @@ STAGES = ("grid_scan", None, "lt_chain_kernel", "per_record")  # lt_batch_phase_
 # kernels rocprofv3 sees per stage (profiles/traffic.json is keyed by kernel name)
 STAGE_KERNELS = {"grid_scan": ("lt_plan_kernel", "lt_scan_kernel", "lt_resolve_kernel"),
                  "lt_chain_kernel": ("lt_chain_kernel",),
-                 "per_record": ("lt_cfo_kernel", "lt_cfo_ring_kernel", "lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")}
+                 "per_record": ("lt_cpsss_kernel", "lt_cp_scan_kernel")}
 INT_FIELDS = ("in_pos", "out_pos", "flags", "peak_pos", "score", "m0", "m1", "n_id_1", "cell_id", "timer")
 EXACT_FLOAT_FIELDS = ("cfo", "mean_cfo", "m_norm_avg", "m_ext_avg", "m0_value", "m1_value")
 METRIC_FIELDS = ("psr", "peak_value", "psr_max")
@@ -387,15 +387,15 @@ def main():
         # what each stage has to read and write at least ("kernel I/O", not the path's algorithmic bytes): the scan
         # rounds read the 9600-sample window of every search once and write 12 x 32 B of partial results per searched
         # window plus one 96-byte record per call; the per-chain kernel only sees chains the rounds could not finish
-        # (none in this workload); the per-record kernels read 128 + 480 + 128 samples per tracked half-frame and
-        # rewrite the records
+        # (none in this workload) and reads the PSS symbol (128 samples) of every tracked half-frame for its CFO estimate;
+        # the per-record kernels read 480 samples per tracked half-frame and rewrite the records
         searched = sum(int(((r["flags"] & lt.F_SEARCHED) != 0).sum()) for r in recs)
         sss_ran = sum(int(((r["flags"] & lt.F_SSS_RAN) != 0).sum()) for r in recs)
         calls = sum(len(r) for r in recs)
         io = {
             "grid_scan": searched * 9600 * 8.0 + searched * 12 * 32.0 + calls * 96.0,
-            "lt_chain_kernel": 0.0,
-            "per_record": sss_ran * (128 + 480 + 128) * 8.0 + calls * 3 * 96.0,
+            "lt_chain_kernel": sss_ran * 128 * 8.0 + calls * 96.0,
+            "per_record": sss_ran * 480 * 8.0 + calls * 2 * 96.0,
         }
         # The arithmetic: a root wave's window is 935 flop per lane (last forward stage, filter spectrum,
         # inverse transform, |.|^2, average), a forward wave's block 450 (two transform stages): per searched window of a

@@ -14,6 +14,7 @@
 #pragma once
 #include <cstddef>
 
+#include "lt_records.h"
 #include "lt_scan_kernels.h"
 
 namespace lt {
@@ -416,7 +417,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       is_tracking = 0;
 #pragma unroll
       for (int t = 0; t < kStripRegs; ++t) ema[t] = 0.f;
-      psr_i = 0; // (d_cfo_i restarts too: lt_cfo_ring_kernel sees the tracking_lost tag this call puts on its half-frame)
+      psr_i = 0; // (d_cfo_i restarts too: the CFO ring of this kernel's tail sees the tracking_lost tag this call puts on its half-frame)
       tracking_lost = 1;
     }
     if (psr > psr_max) psr_max = psr;
@@ -478,30 +479,104 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
 }
 
 // One workgroup per chain: general_work call by call for whatever the scan rounds have left of it (chain_run), then
-// -- every record of the chain is final now -- the chain's tracked half-frames go onto the work list of the
-// per-record kernels (one atomic per 64 records).
+// -- every record of the chain is final now -- what the pss block does with the tracked half-frames besides emitting
+// them (lib/pss_impl.cc:199-204): the CFO estimate of each (eight records per wave at a time) and, in call order, the
+// ring with mean_cfo() (one wave), 768 records per turn; and the chain's tracked half-frames go onto the work list of
+// the per-record kernels (one atomic per 64 records), which rotate them by that mean (lt_kernels.hip).
 __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
 {
   chain_run(a);
   __threadfence_block();
   __syncthreads();
-  const int chain = blockIdx.x, lane = threadIdx.x & 63;
+  const int chain = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // (with two passes: a chain whose records pass 0 left final is listed then; one that waits for the cache, in pass 1)
   ChainState *st = a.state + chain;
   if (st->listed || (a.cache && a.pass == 0 && st->cache_n > 0)) return;
   __syncthreads();
-  if (threadIdx.x == 0) st->listed = 1;
+  if (tid == 0) st->listed = 1;
   const int count = a.rec_count[chain];
-  const lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
-  for (int i = threadIdx.x; i < ((count + 63) & ~63); i += kChainThreads) {
-    const bool ran = i < count && (recs[i].flags & LT_F_SSS_RAN);
-    const unsigned long long m = __ballot(ran);
-    if (!m) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(a.list_count, __builtin_popcountll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (ran) a.list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(chain, i);
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  __shared__ uint32_t t_flags[kChainThreads];
+  __shared__ float t_cfo[kChainThreads];
+  __shared__ int t_idx[kChainThreads];      // the turn's tracked records, compacted: index within the turn ...
+  __shared__ int64_t t_pos[kChainThreads];  // ... and where the half-frame starts
+  __shared__ int t_wave_n[kChainWaves];
+  __shared__ float t_ring[kMovingAvgSz];
+  Capture cap;
+  cap.iq = a.iq + (int64_t)(chain / 3) * a.ch_stride;
+  cap.hist = a.hist ? a.hist + (int64_t)(chain / 3) * a.hist_stride : nullptr;
+  cap.t0 = a.t0;
+  cap.n = a.n;
+  cap.hist_len = a.hist ? a.hist_len : 0;
+  __shared__ v2f t_taps[kSymbolSz];
+  if (tid < kSymbolSz) {
+    const cf32 h = a.tab->pss_taps[chain % 3][tid];
+    t_taps[tid] = v2f{h.re, h.im};
   }
+  const v2f *taps = t_taps; // (visible to every wave after the first barrier of the first turn)
+  CfoRing ring;
+  bool ring_open = false; // (wave 0) the ring has been fetched: only chains with tracked half-frames or lost tracking touch it
+  for (int b0 = 0; b0 < count; b0 += kChainThreads) {
+    const int i = b0 + tid;
+    uint32_t flags = 0u;
+    int64_t out_pos = 0;
+    if (i < count) {
+      flags = recs[i].flags;
+      out_pos = recs[i].out_pos;
+    }
+    const bool ran = (flags & LT_F_SSS_RAN) != 0;
+    const unsigned long long m = __ballot(ran);
+    const int n_w = __builtin_popcountll(m), rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    t_flags[tid] = flags;
+    if (lane == 0) t_wave_n[w] = n_w;
+    if (m) { // the work list of the per-record kernels
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.list_count, n_w);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (ran) a.list[base + rank] = make_int2(chain, i);
+    }
+    __syncthreads();
+    int before = 0, n_ran = 0;
+#pragma unroll
+    for (int k = 0; k < kChainWaves; ++k) {
+      const int c = t_wave_n[k];
+      before += k < w ? c : 0;
+      n_ran += c;
+    }
+    const unsigned long long any_lost = __ballot((flags & LT_F_TAG_LOST) != 0);
+    if (ran) {
+      t_idx[before + rank] = tid;
+      t_pos[before + rank] = out_pos;
+    }
+    __shared__ int t_lost;
+    if (tid == 0) t_lost = 0;
+    __syncthreads();
+    if (any_lost && lane == 0) t_lost = 1; // (benign race: every writer writes 1)
+    // ---- srslte_pss_cfo_compute on the uncorrected PSS symbol of every tracked half-frame (lib/pss_impl.cc:199-201)
+    for (int g = w * 8 + (lane >> 3); g < n_ran; g += kChainWaves * 8) {
+      const int local = t_idx[g];
+      const float c = cfo_estimate_group8(taps, cap, t_pos[g] + (kSlotLen - kSymbolSz), lane);
+      if ((lane & 7) == 0) {
+        t_cfo[local] = c;
+        recs[b0 + local].cfo = c;
+      }
+    }
+    __syncthreads();
+    // ---- d_cfo_data ring, mean_cfo() (lib/pss_impl.cc:94-109,200-204): in call order, one wave
+    if (w == 0 && (n_ran > 0 || t_lost)) {
+      if (!ring_open) {
+        cfo_ring_begin(st, t_ring, ring, lane);
+        ring_open = true;
+      }
+      const int nb = count - b0 < kChainThreads ? count - b0 : kChainThreads;
+      cfo_ring_records(t_ring, ring, nb, lane,
+                       [&](int k, uint32_t &f, float &c) { f = t_flags[k]; c = t_cfo[k]; },
+                       [&](int k, float mean) { recs[b0 + k].mean_cfo = mean; });
+    }
+    __syncthreads();
+  }
+  if (w == 0 && ring_open) cfo_ring_end(st, t_ring, ring, lane);
 }
 
 // ---------------------------------------------------------------- window cache: the lag metric in bulk

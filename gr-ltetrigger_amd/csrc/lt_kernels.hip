@@ -6,11 +6,11 @@
 //                         strip-wise, exponential averages in registers, one forward transform per block shared by the
 //                         chains of a window sequence; pss_impl::general_work (lib/pss_impl.cc:155-223) on the results.
 //   lt_chain_kernel (lt_chain_kernel.h) -- one workgroup per chain: general_work call by call for whatever the rounds
-//                         leave over (and for every chain in mode 0); one lt_record per call.
+//                         leave over (and for every chain in mode 0), one lt_record per call; then, the chain's records
+//                         being final, CFO estimate and mean_cfo() of its tracked half-frames (lib/pss_impl.cc:199-204).
 //   (the per-record kernels walk a work list of the tracked half-frames that lt_chain_kernel leaves behind:)
-//   lt_cfo_kernel, lt_cfo_ring_kernel -- CFO estimate and mean_cfo() of the tracked half-frames (lib/pss_impl.cc:199-204),
-//   lt_cp_kernel, lt_cp_scan_kernel, lt_sss_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) on them, lt_hf_kernel -- the
-//                         pss block's output stream (optional capture): all per record, afterwards (they feed records only).
+//   lt_cpsss_kernel, lt_cp_scan_kernel -- sss_impl::work (lib/sss_impl.cc:83-156) on them, lt_hf_kernel -- the
+//                         pss block's output stream (optional capture): per record, afterwards (they feed records only).
 //   lt_hist_kernel     -- keeps the tail of the chunk for the next lt_batch_push.
 // lt_find_kernel, lt_cfo_*, lt_sync_*  -- single-call forms behind the srslte_* shaped C-ABI.
 // lt_decim_kernel -- decimating FIR in front of the path.
@@ -257,12 +257,29 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_generic_kernel(const v
   y[(int64_t)c * n_out + k] = acc;
 }
 
-// ---------------------------------------------------------------- CP length of the tracked half-frames 
-// srslte_sync_detect_cp (lib/sss_impl.cc:104-108) in two steps.  Its correlations (per half-frame,
-// independent) run one wave per record on the half-frame rotated exactly as srslte_cfo_correct did; its
-// two exponential averages and the decision are a short scan per chain in call order, which also
-// resets them where the reference's sss block sees the tracking_lost tag (lib/sss_impl.cc:91-100) and
-// writes the averages into every record.  Neither feeds the PSS state machine of the per-chain kernel.
+// ---------------------------------------------------------------- the sss block on the tracked half-frames
+// sss_impl::work (lib/sss_impl.cc:83-156) in two launches.  (The pss block's share -- CFO estimate, ring, mean_cfo() --
+// is the per-chain kernel's tail, lt_chain_kernel.h.)
+//   lt_cpsss_kernel   per record, chip-wide (the work list the per-chain kernel left): the half-frame's samples
+//                     [480, 960) rotated exactly as srslte_cfo_correct did (lib/pss_impl.cc:204), the CP correlations
+//                     of srslte_sync_detect_cp (lib/sss_impl.cc:104-106) and srslte_sss_m0m1_partial (:110-116) under
+//                     BOTH CP hypotheses -- which of the two SSS positions counts is only known once the CP averages
+//                     have been run through the chain's records in call order --: metrics and the two (m0, m1) results go
+//                     to the per-record scratch.
+//   lt_cp_scan_kernel per chain, in call order: the two exponential averages of srslte_sync_detect_cp and its decision
+//                     (reset where the sss block sees the tracking_lost tag, lib/sss_impl.cc:91-100), then the SSS result
+//                     of the chosen CP, srslte_sss_N_id_1, cell_id and the tags (lib/sss_impl.cc:118-150).
+// Neither feeds the PSS state machine of the per-chain kernel.
+struct SssPair {
+  int m0, m1;
+  float m0_value, m1_value;
+};
+struct RecordScratch {
+  CpMetrics cp;      // M_norm, M_ext, R_norm, R_ext of this half-frame
+  SssPair sss[2];    // srslte_sss_m0m1_partial with the SSS symbol where a normal / an extended CP puts it
+};
+static_assert(sizeof(RecordScratch) == 48, "RecordScratch layout");
+
 struct CpArgs {
   const v2f *iq;
   int64_t ch_stride;
@@ -272,184 +289,15 @@ struct CpArgs {
   lt_record *recs;      // [n_chains][rec_cap]
   int rec_cap;
   const int *rec_count; // [n_chains]
-  CpMetrics *metrics;   // [n_chains][rec_cap] scratch
+  RecordScratch *scratch; // [n_chains][rec_cap]
   ChainState *state;    // [n_chains]
   const DeviceTables *tab;
   int n_chains;
-  int2 *list;      // (chain, record) of every half-frame that went through the SSS stage in this run
-  int *list_count;
+  const int2 *list;     // (chain, record) of every half-frame that went through the SSS stage in this run
+  const int *list_count;
 };
 
 constexpr int kListBlocks = 2048; // workgroups (x 4 waves) that walk the work list of the tracked half-frames (built by lt_chain_kernel)
-
-// ---------------------------------------------------------------- CFO of the tracked half-frames
-// srslte_pss_cfo_compute on the uncorrected PSS symbol of every tracked half-frame (lib/pss_impl.cc:199-201):
-// independent per record, one wave each.
-__global__ __launch_bounds__(256) void lt_cfo_kernel(CpArgs a)
-{
-  __shared__ v2f RAW[4][kSymbolSz];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n_items = *a.list_count;
-  for (int item = blockIdx.x * 4 + w; item < n_items; item += gridDim.x * 4) {
-    const int2 it = a.list[item];
-    const int chain = __builtin_amdgcn_readfirstlane(it.x), idx = __builtin_amdgcn_readfirstlane(it.y);
-    lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
-    const int64_t hf0 = rec->out_pos;
-    const Capture cap = make_capture(a, chain / 3);
-    for (int i = lane; i < kSymbolSz; i += 64) RAW[w][i] = ld_abs(cap, hf0 + (kSlotLen - kSymbolSz) + i);
-    const float c = cfo_estimate_wave(reinterpret_cast<const v2f *>(a.tab->pss_taps[chain % 3]), RAW[w]);
-    if (lane == 0) rec->cfo = c;
-  }
-}
-
-// d_cfo_data ring and mean_cfo() (lib/pss_impl.cc:94-109,200-204) in call order: one wave per chain.  The ring
-// restarts where reset_score cleared d_cfo_i (lib/pss_impl.cc:145): the call that does so tags its half-frame
-// tracking_lost, and d_cfo_i is 0 whenever a chain is not tracking.
-//
-// compute_moving_avg sums the first min(d_cfo_i, 200) ring entries in index order in double.  While the
-// exponents of all entries seen since the ring restarted span at most 20 binades (no subnormals), every partial
-// sum of any subset is a multiple of the smallest ulp below 2^53 of them: no addition rounds, so the sum is
-// the same in any order -- and it can be carried along (add the new entry, drop the one it overwrites) instead
-// of being formed anew for every call.  Outside that window the sum runs in ring order (moving_avg_wave).
-__global__ __launch_bounds__(64) void lt_cfo_ring_kernel(CpArgs a)
-{
-  __shared__ float ring[kMovingAvgSz];
-  const int chain = blockIdx.x, lane = threadIdx.x;
-  ChainState *st = a.state + chain;
-  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
-  const int count = a.rec_count[chain];
-  for (int i = lane; i < kMovingAvgSz; i += 64) ring[i] = st->cfo_data[i];
-  uint32_t cfo_i = st->cfo_i;
-  // the entries the previous runs left behind: exponent range and (if it is narrow) their exact sum
-  uint32_t emin = 255u, emax = 0u;
-  bool narrow = true;
-  double acc = 0.0;
-  {
-    const uint32_t npts = cfo_i < (uint32_t)kMovingAvgSz ? cfo_i : (uint32_t)kMovingAvgSz;
-    double part = 0.0;
-    uint32_t lmin = 255u, lmax = 0u;
-    bool sub = false;
-    for (uint32_t i = lane; i < npts; i += 64) {
-      const float v = ring[i];
-      const uint32_t bits = __float_as_uint(v) & 0x7fffffffu, e = bits >> 23;
-      if (bits) {
-        sub = sub || e == 0u;
-        lmin = e < lmin ? e : lmin;
-        lmax = e > lmax ? e : lmax;
-      }
-      part += (double)v;
-    }
-    emin = (uint32_t)wave_min_i((int)lmin);
-    emax = (uint32_t)wave_max_i((int)lmax);
-    narrow = !__ballot(sub) && (emax == 0u || (emax - emin <= 20u && emax < 255u));
-    part += lane_xor_d<1>(part); part += lane_xor_d<2>(part); part += lane_xor_d<4>(part);
-    part += lane_xor_d<8>(part); part += lane_xor_d<16>(part); part += lane_xor_d<32>(part);
-    acc = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)), __builtin_amdgcn_readfirstlane(__double2loint(part)));
-  }
-  uint32_t flags_n = lane < count ? recs[lane].flags : 0u;
-  float cfo_n = lane < count ? recs[lane].cfo : 0.f; // (fetched with the flags, and a block ahead)
-  for (int base = 0; base < count; base += 64) {
-    const int i = base + lane;
-    const uint32_t flags = flags_n;
-    const bool is_ran = (flags & LT_F_SSS_RAN) != 0;
-    const float c = is_ran ? cfo_n : 0.f;
-    {
-      const int in = i + 64;
-      flags_n = in < count ? recs[in].flags : 0u;
-      cfo_n = in < count ? recs[in].cfo : 0.f;
-    }
-    const unsigned long long ran = __ballot(is_ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
-    if (!ran && !lost) continue;
-    // ---- the 64 records at once.  While the exponent window holds for every entry up to the last of these
-    // records, all the sums are exact whatever their order: record j's sum is the carried one plus the entries
-    // of the records up to j minus the ring entries those overwrite -- two prefix sums across the lanes.
-    if (narrow && !lost) {
-      const uint32_t bits = __float_as_uint(c) & 0x7fffffffu, e = bits >> 23;
-      const bool counts = is_ran && bits != 0u;
-      const uint32_t bmin = (uint32_t)wave_min_i(counts ? (int)e : 255), bmax = (uint32_t)wave_max_i(counts ? (int)e : 0);
-      const uint32_t nmin = bmin < emin ? bmin : emin, nmax = bmax > emax ? bmax : emax;
-      const bool sub = __ballot(counts && e == 0u) != 0;
-      if (!sub && (nmax == 0u || (nmax - nmin <= 20u && nmax < 255u))) {
-        const uint32_t rank = (uint32_t)__builtin_popcountll(ran & ((1ull << lane) - 1ull));
-        const uint32_t idx = cfo_i + rank; // this record's entry (if it has one)
-        const uint32_t slot = idx % kMovingAvgSz;
-        double add = is_ran ? (double)c : 0.0;
-        double drop = (is_ran && idx >= (uint32_t)kMovingAvgSz) ? (double)ring[slot] : 0.0; // the entry it overwrites
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const double a2 = __hiloint2double(__shfl_up(__double2hiint(add), d), __shfl_up(__double2loint(add), d));
-          const double d2 = __hiloint2double(__shfl_up(__double2hiint(drop), d), __shfl_up(__double2loint(drop), d));
-          if (lane >= d) {
-            add += a2;
-            drop += d2;
-          }
-        }
-        const double mine_acc = (acc + add) - drop;
-        const uint32_t npts = idx + 1 < (uint32_t)kMovingAvgSz ? idx + 1 : (uint32_t)kMovingAvgSz;
-        __builtin_amdgcn_wave_barrier();
-        if (is_ran) {
-          ring[slot] = c; // (64 records at most, 200 slots: no two of them share one)
-          recs[i].mean_cfo = (float)(mine_acc / (double)npts);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int last = 63 - __builtin_clzll(ran);
-        acc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine_acc), last), __builtin_amdgcn_readlane(__double2loint(mine_acc), last));
-        cfo_i += (uint32_t)__builtin_popcountll(ran);
-        emin = nmin;
-        emax = nmax;
-        continue;
-      }
-    }
-    // ---- in call order, one record after the other
-    unsigned long long events = ran | lost;
-    float mine = 0.f;
-    double my_acc = 0.0; // narrow mode: this lane's record's sum and count; the division waits until after the walk
-    uint32_t my_n = 0;
-    while (events) {
-      const int j = __builtin_ctzll(events);
-      events &= events - 1;
-      if ((lost >> j) & 1) {
-        cfo_i = 0;
-        emin = 255u; emax = 0u; narrow = true; acc = 0.0;
-      }
-      if ((ran >> j) & 1) {
-        const float cj = rlane(c, j);
-        const uint32_t slot = cfo_i % kMovingAvgSz;
-        const uint32_t npts = cfo_i + 1 < (uint32_t)kMovingAvgSz ? cfo_i + 1 : (uint32_t)kMovingAvgSz;
-        const uint32_t bits = __float_as_uint(cj) & 0x7fffffffu, e = bits >> 23;
-        if (bits) {
-          if (e == 0u) narrow = false;
-          emin = e < emin ? e : emin;
-          emax = e > emax ? e : emax;
-          if (emax - emin > 20u || emax >= 255u) narrow = false;
-        }
-        if (narrow) {
-          if (cfo_i >= (uint32_t)kMovingAvgSz) acc -= (double)ring[slot]; // the entry this call overwrites
-          acc += (double)cj;
-          if (lane == j) {
-            my_acc = acc;
-            my_n = npts;
-          }
-        } else {
-          const float mc = moving_avg_wave(ring, cfo_i + 1, slot, cj);
-          if (lane == j) {
-            mine = mc;
-            my_n = 0;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) ring[slot] = cj;
-        __builtin_amdgcn_wave_barrier();
-        cfo_i++;
-      }
-    }
-    if (my_n) mine = (float)(my_acc / (double)my_n);
-    if (i < count && (flags & LT_F_SSS_RAN)) recs[i].mean_cfo = mine;
-  }
-  for (int i = lane; i < kMovingAvgSz; i += 64) st->cfo_data[i] = ring[i];
-  if (lane == 0) st->cfo_i = cfo_i;
-}
 
 // The pss block's output stream (optional capture, lt_batch_enable_halfframes): every emitted half-frame,
 // CFO-corrected when tracking (lib/pss_impl.cc:188-193,204).  One workgroup per record.
@@ -493,112 +341,10 @@ __global__ __launch_bounds__(256) void lt_hf_kernel(HfArgs a)
   }
 }
 
-__global__ __launch_bounds__(256) void lt_cp_kernel(CpArgs a)
-{
-  __shared__ v2f S[4][kSssLen];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n_items = *a.list_count;
-  for (int item = blockIdx.x * 4 + w; item < n_items; item += gridDim.x * 4) {
-    const int2 it = a.list[item];
-    const int chain = __builtin_amdgcn_readfirstlane(it.x), idx = __builtin_amdgcn_readfirstlane(it.y);
-    const lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
-    const int64_t hf0 = rec->out_pos;
-    const Capture cap = make_capture(a, chain / 3);
-    const float freq = -rec->mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
-    const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-    for (int i = lane; i < kSssLen; i += 64)
-      S[w][i] = cfo_rotate(a.tab->cexptab, phase_inc, kSssBase + i, ld_abs(cap, hf0 + kSssBase + i));
-    const CpMetrics cm = cp_metrics_wave(S[w]);
-    if (lane == 0) a.metrics[(int64_t)chain * a.rec_cap + idx] = cm;
-  }
-}
-
-// One wave per chain: 64 records at a time are fetched one per lane and everything that does not depend on
-// the running averages is formed in parallel; the wave then walks only the records that change the
-// averages (tracked half-frames, tracking_lost tags) in call order with wave-uniform arithmetic, every lane
-// keeping the state as of its own record; decisions and stores are per lane again.
-__global__ __launch_bounds__(64) void lt_cp_scan_kernel(CpArgs a)
-{
-  const int chain = blockIdx.x, lane = threadIdx.x;
-  ChainState *st = a.state + chain;
-  float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
-  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
-  const CpMetrics *cm = a.metrics + (int64_t)chain * a.rec_cap;
-  const int count = a.rec_count[chain];
-  // (a record's flags and its metrics are fetched together, and the next 64 records' while this block is walked: the
-  // scratch entry of a record that is no tracked half-frame holds whatever an earlier run left there and is not looked at)
-  uint32_t flags_n = lane < count ? recs[lane].flags : 0u;
-  CpMetrics c_n = lane < count ? cm[lane] : CpMetrics{};
-  for (int base = 0; base < count; base += 64) {
-    const int i = base + lane;
-    const bool valid = i < count;
-    const uint32_t flags = flags_n;
-    const bool ran = (flags & LT_F_SSS_RAN) != 0;
-    CpMetrics c = c_n;
-    if (!ran) c.m[0] = c.m[1] = c.r[0] = c.r[1] = 0.f;
-    {
-      const int in = i + 64;
-      flags_n = in < count ? recs[in].flags : 0u;
-      if (in < count) c_n = cm[in];
-    }
-    const float in_norm = cp_avg_input(c.m[0]), in_ext = cp_avg_input(c.m[1]);
-    const unsigned long long run = __ballot(ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
-    float my_norm = m_norm_avg, my_ext = m_ext_avg; // state as of this lane's record
-    unsigned long long events = run | lost;
-    while (events) {
-      const int j = __builtin_ctzll(events);
-      events &= events - 1;
-      if ((lost >> j) & 1) { // the sss block resets on the tracking_lost tag (lib/sss_impl.cc:91-100)
-        m_norm_avg = 0.f;
-        m_ext_avg = 0.f;
-      }
-      if ((run >> j) & 1) {
-        m_norm_avg = cp_avg_step(rlane(in_norm, j), m_norm_avg);
-        m_ext_avg = cp_avg_step(rlane(in_ext, j), m_ext_avg);
-      }
-      if (lane >= j) {
-        my_norm = m_norm_avg;
-        my_ext = m_ext_avg;
-      }
-    }
-    if (valid) {
-      recs[i].m_norm_avg = my_norm;
-      recs[i].m_ext_avg = my_ext;
-      if (ran && cp_choose(my_norm, my_ext, c.r[0], c.r[1]) == LT_CP_EXT) recs[i].flags = flags | LT_F_CP_EXT;
-    }
-  }
-  if (lane == 0) {
-    st->m_norm_avg = m_norm_avg;
-    st->m_ext_avg = m_ext_avg;
-  }
-}
-
-// ---------------------------------------------------------------- SSS of the tracked half-frames 
-// srslte_sss_m0m1_partial + srslte_sss_N_id_1 (lib/sss_impl.cc:110-124) of every record whose half-frame
-// went through the SSS stage.  The per-chain kernel has done the sequential part (CFO ring mean; the CP
-// averages and decision) and left mean_cfo and the CP flag in the record; m0 / m1 / N_id_1 / cell_id feed
-// nothing but the record, so they are computed here for all chains at once, one wave per record: rotate
-// the SSS symbol exactly as srslte_cfo_correct did (same table index, same products), FFT-128,
-// 31 + 31 correlations, table look-up -- the same device functions the fused kernel runs in line.
-struct SssArgs {
-  const v2f *iq;
-  int64_t ch_stride;
-  const v2f *hist;
-  int64_t hist_stride;
-  int64_t t0, n, hist_len;
-  lt_record *recs;  // [n_chains][rec_cap]
-  int rec_cap;
-  const int *rec_count; // [n_chains]
-  const DeviceTables *tab;
-  const int2 *list;     // as CpArgs
-  const int *list_count;
-};
-
-__global__ __launch_bounds__(256) void lt_sss_kernel(SssArgs a)
+__global__ __launch_bounds__(256) void lt_cpsss_kernel(CpArgs a)
 {
   __shared__ LdsTables ltab[4]; // (the m-sequence masks depend on the chain's N_id_2: one set per wave)
-  __shared__ v2f SYM[4][kSymbolSz];
+  __shared__ v2f S[4][kSssLen];
   __shared__ v2f Y[4][62];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -613,42 +359,148 @@ __global__ __launch_bounds__(256) void lt_sss_kernel(SssArgs a)
     const int2 it = a.list[item];
     const int chain = __builtin_amdgcn_readfirstlane(it.x), idx = __builtin_amdgcn_readfirstlane(it.y);
     const int n_id_2 = chain % 3;
-    lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
-    const uint32_t flags = rec->flags;
+    const lt_record *rec = a.recs + (int64_t)chain * a.rec_cap + idx;
     const int64_t hf0 = rec->out_pos;
-    const float mean_cfo = rec->mean_cfo;
     const Capture cap = make_capture(a, chain / 3);
-    const float freq = -mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
+    const float freq = -rec->mean_cfo / (float)kSymbolSz; // lib/pss_impl.cc:204
     const float phase_inc = __fmul_rn(freq, (float)kCexpTabSize);
-    const int cp_len = (flags & LT_F_CP_EXT) ? 32 : 9;              // srslte_sync_set_cp
-    const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len;           // lib/sss_impl.cc:110
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
       ltab[w].c0_mask = a.tab->sss_c0_mask[n_id_2];
       ltab[w].c1_mask = a.tab->sss_c1_mask[n_id_2];
     }
+    {
+      const int64_t i0 = hf0 + kSssBase - cap.t0;
+      if (i0 >= 0 && i0 + kSssLen <= cap.n) { // inside the chunk (always, but for a half-frame across the start of a pushed chunk)
+        const v2f *__restrict__ p = cap.iq + i0 + lane;
+        v2f v[(kSssLen + 63) / 64];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = sss_idx + lane + 64 * k;
-      SYM[w][lane + 64 * k] = cfo_rotate(a.tab->cexptab, phase_inc, i, ld_abs(cap, hf0 + i));
-    }
-    __builtin_amdgcn_wave_barrier();
-    SssResult r;
-    r.cp = 0;
-    sss_fft128_wave(SYM[w], ltab[w].tw128, Y[w]);
-    sss_m0m1_wave(Y[w], ltab[w], r);
-    r.n_id_1 = sss_n_id_1(a.tab, (uint32_t)r.m0, (uint32_t)r.m1);
-    if (lane == 0) {
-      rec->m0 = r.m0;
-      rec->m1 = r.m1;
-      rec->m0_value = r.m0_value;
-      rec->m1_value = r.m1_value;
-      rec->n_id_1 = r.n_id_1;
-      if (r.n_id_1 >= 0) {
-        rec->cell_id = 3 * r.n_id_1 + n_id_2; // srslte_sync_get_cell_id
-        rec->flags = flags | LT_F_TAG_CELL;
+        for (int k = 0; k < (kSssLen + 63) / 64; ++k) v[k] = (lane + 64 * k < kSssLen) ? p[64 * k] : v2f{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < (kSssLen + 63) / 64; ++k)
+          if (lane + 64 * k < kSssLen) S[w][lane + 64 * k] = cfo_rotate(a.tab->cexptab, phase_inc, kSssBase + lane + 64 * k, v[k]);
+      } else {
+        for (int i = lane; i < kSssLen; i += 64)
+          S[w][i] = cfo_rotate(a.tab->cexptab, phase_inc, kSssBase + i, ld_abs(cap, hf0 + kSssBase + i));
       }
     }
+    __builtin_amdgcn_wave_barrier();
+    RecordScratch out;
+    out.cp = cp_metrics_wave(S[w]);
+#pragma unroll
+    for (int hyp = 0; hyp < 2; ++hyp) {
+      const int cp_len = hyp ? 32 : 9;                                   // srslte_sync_set_cp
+      const int sss_idx = kSlotLen - 2 * kSymbolSz - cp_len - kSssBase;  // lib/sss_impl.cc:110
+      SssResult r;
+      r.cp = hyp;
+      __builtin_amdgcn_wave_barrier();
+      sss_fft128_wave(S[w] + sss_idx, ltab[w].tw128, Y[w]);
+      __builtin_amdgcn_wave_barrier();
+      sss_m0m1_wave(Y[w], ltab[w], r);
+      out.sss[hyp].m0 = r.m0;
+      out.sss[hyp].m1 = r.m1;
+      out.sss[hyp].m0_value = r.m0_value;
+      out.sss[hyp].m1_value = r.m1_value;
+    }
+    if (lane == 0) a.scratch[(int64_t)chain * a.rec_cap + idx] = out;
+  }
+}
+
+// One wave per chain: 64 records at a time are fetched one per lane and everything that does not depend on
+// the running averages is formed in parallel; two lanes then run the two averages through the block's records in call
+// order; decisions, the choice between the two SSS results and the stores are per lane again.
+__global__ __launch_bounds__(64) void lt_cp_scan_kernel(CpArgs a)
+{
+  __shared__ float s_in[2][64], s_out[2][64];
+  __shared__ uint32_t s_ev[64];
+  const int chain = blockIdx.x, lane = threadIdx.x;
+  const int n_id_2 = chain % 3;
+  ChainState *st = a.state + chain;
+  float m_norm_avg = st->m_norm_avg, m_ext_avg = st->m_ext_avg;
+  lt_record *recs = a.recs + (int64_t)chain * a.rec_cap;
+  const RecordScratch *sc = a.scratch + (int64_t)chain * a.rec_cap;
+  const int count = a.rec_count[chain];
+  // (a record's flags and its scratch entry are fetched together, and the next 64 records' while this block is walked: the
+  // scratch entry of a record that is no tracked half-frame holds whatever an earlier run left there and is not looked at)
+  uint32_t flags_n = lane < count ? recs[lane].flags : 0u;
+  RecordScratch c_n = lane < count ? sc[lane] : RecordScratch{};
+  for (int base = 0; base < count; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < count;
+    const uint32_t flags = flags_n;
+    const bool ran = (flags & LT_F_SSS_RAN) != 0;
+    RecordScratch c = c_n;
+    if (!ran) c.cp.m[0] = c.cp.m[1] = c.cp.r[0] = c.cp.r[1] = 0.f;
+    {
+      const int in = i + 64;
+      flags_n = in < count ? recs[in].flags : 0u;
+      if (in < count) c_n = sc[in];
+    }
+    const float in_norm = cp_avg_input(c.cp.m[0]), in_ext = cp_avg_input(c.cp.m[1]);
+    const unsigned long long run = __ballot(ran), lost = __ballot((flags & LT_F_TAG_LOST) != 0);
+    float my_norm = m_norm_avg, my_ext = m_ext_avg; // state as of this lane's record
+    if (run | lost) {
+      // The two averages are sequential in the records; everything else is not.  Inputs and event bits go to LDS, lane 0
+      // runs M_norm_avg and lane 1 M_ext_avg through the 64 records (eight at a time: the reads of a group are in flight
+      // together, the recurrence itself is two dependent operations per record), every lane then picks up the state as
+      // of its own record.  A tracking_lost tag resets first (lib/sss_impl.cc:91-100), a tracked half-frame then steps.
+      s_in[0][lane] = in_norm;
+      s_in[1][lane] = in_ext;
+      s_ev[lane] = (ran ? 1u : 0u) | ((flags & LT_F_TAG_LOST) ? 2u : 0u);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 2) {
+        float avg = lane ? m_ext_avg : m_norm_avg;
+        const float *in = s_in[lane];
+        float *out = s_out[lane];
+#pragma unroll 1
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+          float x[8];
+          uint32_t e[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            x[k] = in[j0 + k];
+            e[k] = s_ev[j0 + k];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            avg = (e[k] & 2u) ? 0.f : avg;
+            const float stepped = cp_avg_step(x[k], avg);
+            avg = (e[k] & 1u) ? stepped : avg;
+            out[j0 + k] = avg;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      my_norm = s_out[0][lane];
+      my_ext = s_out[1][lane];
+      m_norm_avg = s_out[0][63];
+      m_ext_avg = s_out[1][63];
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (valid) {
+      recs[i].m_norm_avg = my_norm;
+      recs[i].m_ext_avg = my_ext;
+      if (ran) {
+        const bool ext = cp_choose(my_norm, my_ext, c.cp.r[0], c.cp.r[1]) == LT_CP_EXT;
+        const SssPair r = ext ? c.sss[1] : c.sss[0];
+        const int n_id_1 = sss_n_id_1(a.tab, (uint32_t)r.m0, (uint32_t)r.m1); // lib/sss_impl.cc:118
+        uint32_t f = flags | (ext ? LT_F_CP_EXT : 0u);
+        recs[i].m0 = r.m0;
+        recs[i].m1 = r.m1;
+        recs[i].m0_value = r.m0_value;
+        recs[i].m1_value = r.m1_value;
+        recs[i].n_id_1 = n_id_1;
+        if (n_id_1 >= 0) {
+          recs[i].cell_id = 3 * n_id_1 + n_id_2; // srslte_sync_get_cell_id
+          f |= LT_F_TAG_CELL;
+        }
+        if (f != flags) recs[i].flags = f;
+      }
+    }
+  }
+  if (lane == 0) {
+    st->m_norm_avg = m_norm_avg;
+    st->m_ext_avg = m_ext_avg;
   }
 }
 
@@ -710,15 +562,15 @@ int scan_counter_ints() { return kCtrLaunchSlots + kMaxRounds + 2; }
 int cache_counter_index() { return kCtrSlots; } // job counters of every round + the per-record work lists' + the window cache's
 int cache_slot_bytes() { return (int)(cache_slot_floats() * sizeof(float)); }
 int cache_max_per_chain() { return kCacheMaxPerChain; }
-int per_record_scratch_bytes() { return (int)(sizeof(CpMetrics) + 2 * sizeof(int2)); } // CP metrics + one work-list entry for each of the two list slots
+int per_record_scratch_bytes() { return (int)(sizeof(RecordScratch) + 2 * sizeof(int2)); } // CP metrics and SSS results + one work-list entry for each of the two list slots
 
-// The work lists sit behind the CP metrics in the per-record scratch buffer, one per list slot (their counters
+// The work lists sit behind the CP metrics and SSS results in the per-record scratch buffer, one per list slot (their counters
 // behind the job counters): with lt_batch_set_overlap the per-chain kernel of run k + 1 fills its list on the main
 // stream while the per-record kernels of run k still walk theirs on the side stream.
 static int2 *work_list(const RunLaunch &R, int n_chains)
 {
   const size_t per_slot = (size_t)n_chains * (size_t)R.rec_cap;
-  return reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(CpMetrics) * per_slot) + (R.list_slot ? per_slot : 0);
+  return reinterpret_cast<int2 *>(reinterpret_cast<char *>(R.cp_scratch) + sizeof(RecordScratch) * per_slot) + (R.list_slot ? per_slot : 0);
 }
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t records_stream)
@@ -932,20 +784,12 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     CpArgs c;
     c.iq = iq; c.ch_stride = R.ch_stride; c.hist = hist; c.hist_stride = R.hist_stride; c.t0 = R.t0; c.n = R.n;
     c.hist_len = R.hist_len; c.recs = R.recs; c.rec_cap = R.rec_cap; c.rec_count = R.rec_count;
-    c.metrics = reinterpret_cast<CpMetrics *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
+    c.scratch = reinterpret_cast<RecordScratch *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
     c.list = work_list(R, n_chains);
     c.list_count = R.n_jobs + kCtrList + (R.list_slot ? 1 : 0);
-    SssArgs q;
-    q.iq = iq; q.ch_stride = R.ch_stride; q.hist = hist; q.hist_stride = R.hist_stride; q.t0 = R.t0; q.n = R.n;
-    q.hist_len = R.hist_len; q.recs = R.recs; q.rec_cap = R.rec_cap; q.rec_count = R.rec_count; q.tab = R.tab;
-    q.list = c.list; q.list_count = c.list_count;
-    const dim3 per_record((unsigned)kListBlocks);
     if (R.records_delay_us > 0) hipLaunchKernelGGL(lt_delay_kernel, dim3(1), dim3(64), 0, rs, (long long)R.records_delay_us * 100);
-    hipLaunchKernelGGL(lt_cfo_kernel, per_record, dim3(256), 0, rs, c);
-    hipLaunchKernelGGL(lt_cfo_ring_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
-    hipLaunchKernelGGL(lt_cp_kernel, per_record, dim3(256), 0, rs, c);
+    hipLaunchKernelGGL(lt_cpsss_kernel, dim3((unsigned)kListBlocks), dim3(256), 0, rs, c);
     hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
-    hipLaunchKernelGGL(lt_sss_kernel, per_record, dim3(256), 0, rs, q);
     if (R.out_hf && R.out_cap > 0) {
       HfArgs h;
       h.iq = iq; h.ch_stride = R.ch_stride; h.hist = hist; h.hist_stride = R.hist_stride; h.t0 = R.t0; h.n = R.n;
@@ -965,7 +809,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
 }
 
 // lt_batch_reset: the chains back to their constructor state.  The members only the per-record kernels
-// touch (CFO ring, CP averages) are cleared separately, so that with lt_batch_set_overlap they can be cleared on the
+// touch (the CP averages; the CFO ring is the per-chain kernel's) are cleared separately, so that with lt_batch_set_overlap they can be cleared on the
 // stream those kernels run on, behind the previous run's.  parts: 1 = everything else, 2 = those members, 3 = all.
 __global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int parts, int *rec_count)
 {
@@ -973,12 +817,11 @@ __global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int pa
   uint32_t *w = reinterpret_cast<uint32_t *>(state + blockIdx.x);
   // everything in front of the three average buffers; those are not cleared but declared zero (ema_zero = 2)
   constexpr int n = (int)(offsetof(ChainState, avg) / 4);
-  constexpr int i_cfo = (int)(offsetof(ChainState, cfo_i) / 4), i_norm = (int)(offsetof(ChainState, m_norm_avg) / 4);
-  constexpr int i_ext = (int)(offsetof(ChainState, m_ext_avg) / 4), i_ring = (int)(offsetof(ChainState, cfo_data) / 4);
+  constexpr int i_norm = (int)(offsetof(ChainState, m_norm_avg) / 4), i_ext = (int)(offsetof(ChainState, m_ext_avg) / 4);
   constexpr int i_zero = (int)(offsetof(ChainState, ema_zero) / 4);
   static_assert(offsetof(ChainState, avg) % 4 == 0, "ChainState is cleared word by word");
   for (int i = threadIdx.x; i < n; i += 256) {
-    const bool rec = i == i_cfo || i == i_norm || i == i_ext || (i >= i_ring && i < i_ring + kMovingAvgSz);
+    const bool rec = i == i_norm || i == i_ext; // (the CFO ring is the per-chain kernel's: lt_chain_kernel.h)
     if (parts & (rec ? 2 : 1)) w[i] = i == i_zero ? 2u : 0u;
   }
 }

@@ -29,8 +29,7 @@ def counter(run, kernel_substr, name, per_run=False):
     return vals
 
 
-KERNELS = ("lt_plan_kernel", "lt_scan_kernel", "lt_resolve_kernel", "lt_chain_kernel", "lt_cfo_kernel", "lt_cfo_ring_kernel",
-           "lt_cp_kernel", "lt_cp_scan_kernel", "lt_sss_kernel")
+KERNELS = ("lt_plan_kernel", "lt_scan_kernel", "lt_resolve_kernel", "lt_chain_kernel", "lt_cpsss_kernel", "lt_cp_scan_kernel")
 POST = ()
 
 
