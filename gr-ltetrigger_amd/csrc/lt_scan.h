@@ -106,14 +106,24 @@ __device__ __forceinline__ int wave_min_key_dpp(int k)
 // strip's maximum is the wave maximum of m.  The maximum outside the main lobe needs no second pass: the 64 lags
 // around the peak are one value per lane (`row`); outside that window a lane contributes m -- or m2 where its
 // maximum IS its window value --, inside it the window value unless the lobe covers it.
-__device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, StripPartial &out)
+// ... in two steps, so that a caller that sees all twelve strips of a window (the per-chain kernel) can stop after the
+// first for every strip but the one that holds the window's peak: strip_peak = the strip's maximum and where it sits,
+// strip_lobe = the main lobe around it and the maximum outside.  strip_resolve = both.
+struct StripPeak {
+  float m, m2;    // per lane: maximum over its owned lags, second largest
+  int a;          // per lane: the register the maximum sits in
+  float M1;       // the strip's maximum (wave-uniform, like everything below)
+  int l_p, r_p;   // lane and register of its first occurrence
+  int p1;         // its lag
+  uint32_t flags; // kPartWide: no maximum found (a NaN)
+};
+__device__ __forceinline__ void strip_peak(const ema_t &e, int s, int lane, StripPeak &k)
 {
   const int c0 = kStripPitch * s - kStripHalo;
   // owned and valid lags: offsets [41, 852) of the computed range, lag < 9726 (strip 11 ends at offset 845):
   // the halo lags in registers 0 and 13 sit out the two maxima
   const int own13_end = (s == kStrips - 1) ? (kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13)
                                            : (kStripHalo + kStripPitch - 64 * 13);
-  const uint64_t halo0 = (1ull << kStripHalo) - 1ull, halo13 = ~((1ull << own13_end) - 1ull); // lanes of register 0 / 13 that sit out
   const bool own0 = lane >= kStripHalo, own13 = lane < own13_end;
   // 1. per lane: maximum, its register (the first), second largest
   float m = own0 ? e[0] : -FLT_MAX, m2 = -FLT_MAX;
@@ -148,7 +158,16 @@ __device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, S
     r_p = 0;
     flags = kPartWide;
   }
-  const int p1 = c0 + l_p + 64 * r_p;
+  k.m = m; k.m2 = m2; k.a = a; k.M1 = M1; k.l_p = l_p; k.r_p = r_p; k.p1 = c0 + l_p + 64 * r_p; k.flags = flags;
+}
+__device__ __forceinline__ void strip_lobe(const ema_t &e, int s, int lane, const StripPeak &k, StripPartial &out)
+{
+  const int own13_end = (s == kStrips - 1) ? (kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13)
+                                           : (kStripHalo + kStripPitch - 64 * 13);
+  const uint64_t halo0 = (1ull << kStripHalo) - 1ull, halo13 = ~((1ull << own13_end) - 1ull); // lanes of register 0 / 13 that sit out
+  const float m = k.m, m2 = k.m2, M1 = k.M1;
+  const int l_p = k.l_p, r_p = k.r_p, p1 = k.p1;
+  uint32_t flags = k.flags;
   // 2. the lags p1 - 32 .. p1 + 31 as one rotated row: lane L holds offset (L - l_p) wrapped to [-32, 32).
   // Offsets that fall off this register's 64 lanes come from the register before (l_p < 32) or after it
   // (which exists whenever a lane needs it: the peak is an owned lag).
@@ -197,6 +216,13 @@ __device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, S
   out.a0 = (s == 0) ? rlane(e[0], kStripHalo) : 0.f;
   out.flags = flags;
   out.pad = 0;
+}
+
+__device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, StripPartial &out)
+{
+  StripPeak k;
+  strip_peak(e, s, lane, k);
+  strip_lobe(e, s, lane, k, out);
 }
 
 struct WindowResult {
