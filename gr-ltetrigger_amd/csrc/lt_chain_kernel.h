@@ -93,25 +93,41 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
 // barriers; `buf` alternates between calls.
 // cached: the window's lag metric as lt_metric_kernel left it (12 x 896 floats) -- the transforms are skipped, the
 // average and everything after it run as ever (x is not looked at then).
-//
-// (Round 3 pulled the NEXT slot's lines into the L2 during a cached search with fourteen loads into a sink register that
-// were left in flight past their block of assembly: worth 7 % of a step at 0 dB -- and a register the compiler is free to
-// reuse under them (an instrumented build of this kernel faulted).  Removed.  Safe forms measured on one box
-// against it, per-chain kernel of a 64-channel step at -4 / 0 dB: none 2.00 / 1.30 ms (this code); the same loads closed
-// by a wait of their own 2.17 / 1.40 (the search waits for the next slot's HBM latency); one or two LDS-DMA loads, a
-// sector per lane, into a dump area 2.16 / 1.33 and 2.12 / 1.36 (an LDS-DMA instruction costs the wave ~300 cycles to
-// issue); LDS-DMA of the whole strip into the idle exchange area 1.95 / 1.27; the unsafe form 1.85 / 1.20.)
-
+// Round 3 pulled the NEXT slot's lines into the L2 during a cached search, with fourteen loads into one register that
+// nobody reads, left in flight past their block of assembly -- a register the compiler is free to reuse under them
+// (an instrumented build of this kernel faulted).  The loads are gone; measured on one box against the
+// version with them, per-chain kernel of a 64-channel step at -4 / 0 dB: 1.92 / 1.21 ms without, 1.91 / 1.21 with --
+// they bought nothing.  What is left of the mechanism is the plain wait at the top of the search after a cached one.
+// (Safe prefetches that were measured and do not pay: the same loads closed by a wait of their own, +15 %: the search
+// then waits for the next slot's HBM latency; one or two LDS-DMA loads, a sector per lane, into a dump area, +8 %; LDS-DMA
+// of the whole strip into the wave's idle exchange area, +3 %: an LDS-DMA instruction costs the wave ~300 cycles to issue.)
+struct WarmUp {
+  float sink = 0.f;
+  bool on = false;
+};
+__device__ __forceinline__ void warm_up_landed(WarmUp &wu)
+{
+  if (wu.on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wu.sink)::"memory");
+  wu.on = false;
+}
 __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane, ema_t &ema, int &buf,
-                                                     bool resolve, const float *cached = nullptr,
+                                                     bool resolve, WarmUp &wu, const float *cached = nullptr,
                                                      const float *cache_end = nullptr)
 {
   fft::c32 *e = L.E + w * fft::kScratchW;
+  warm_up_landed(wu);
   if (cached) {
     float met[kStripRegs];
     const float *m = cached + (size_t)w * kCacheStripLags + lane;
 #pragma unroll
     for (int r = 0; r < kStripRegs; ++r) met[r] = m[64 * r];
+    // The slot after this one is what the chain will want next if it stays on its grid: its lines are pulled into
+    // this XCD's L2 now, so that the search after this one finds them there instead of in HBM (WarmUp above).
+    if (cached + cache_slot_floats() < cache_end) {
+      const float *n = m + cache_slot_floats();
+      wu.on = true;
+      (void)n; // (round 3 issued fourteen loads into wu.sink here and left them in flight: removed, see below)
+    }
     strip_ema_apply(w, lane, met, ema);
   } else {
     strip_fft<false>(lane, x, L.TW1, L.TW2, e);
@@ -128,49 +144,7 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[
   buf ^= 1;
   if (lane == 0) parts[w] = p;
   __syncthreads();
-  // resolve_window (lt_scan.h) with lane s < 12 looking after strip s: one LDS round trip fetches all twelve partials, a
-  // reduction inside the first row of sixteen lanes finds the largest maximum, the first lane that holds it is the peak's
-  // strip (strips ascend in lag: the first maximum); a second reduction gives the largest value outside the lobe.  (Read
-  // strip after strip by every lane, the twelve partials were some twenty dependent LDS round trips: 2 400 cycles of the
-  // 8 000 a search from the cache took.)
-  WindowResult r;
-  {
-    const bool is_strip = lane < kStrips;
-    const StripPartial q = parts[is_strip ? lane : 0];
-    const float m1_s = is_strip ? q.m1 : -FLT_MAX;
-    float bm = m1_s;
-    asm("s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-        : "+v"(bm));
-    bm = rlane(bm, 0);
-    const uint64_t at_max = __ballot(is_strip && m1_s == bm);
-    const int best = at_max ? __builtin_ctzll(at_max) : 0; // (no lane only if a maximum is a NaN: outside the contract)
-    const uint32_t bflags = (uint32_t)__builtin_amdgcn_readlane((int)q.flags, best);
-    const int lb = __builtin_amdgcn_readlane(q.lb, best), ub = __builtin_amdgcn_readlane(q.ub, best);
-    r.exact = !(bflags & kPartWide);
-    r.peak_value = bm;
-    r.peak_pos = (bm > -FLT_MAX) ? __builtin_amdgcn_readlane(q.p1, best) : 0; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
-    const bool other = is_strip && lane != best;
-    const bool inside = other && q.p1 >= lb && q.p1 < ub; // that strip's maximum lies on the slope of this lobe
-    if (__ballot(inside && (q.flags & kPartWide))) r.exact = false;
-    float o = !is_strip ? -FLT_MAX : ((lane == best || inside) ? q.s : m1_s);
-    asm("s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-        : "+v"(o));
-    o = rlane(o, 0);
-    // empty ranges stand for their first element: the left one is empty exactly when the peak sits at lag <= 2,
-    // the right one when the lobe reaches lag 9726 (avg[9726..9727] = 0)
-    const float sl = (r.peak_pos <= 2) ? rlane(q.a0, 0) : o;
-    const float sr = (ub >= kNLags) ? 0.f : o;
-    const float side = sl > sr ? sl : sr;
-    r.psr = r.peak_value / side;
-  }
+  const WindowResult r = resolve_window_unrolled(parts); // (the reads of a loop in flight together, not in turn)
   out.peak_pos = __builtin_amdgcn_readfirstlane(r.peak_pos);
   out.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.peak_value)));
   out.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.psr)));
@@ -301,6 +275,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
     cache_n = st->cache_n;
   }
   const float *cache_end = cache0 ? cache0 + (size_t)cache_n * cache_slot_floats() : nullptr;
+  WarmUp warm;
   int64_t cache_next_pos = cache_pos; // the window of slot cache_next_k: where a chain that stays on its grid searches next
   int cache_next_k = 0;
 
@@ -328,7 +303,6 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
   const int call_base = st->n_calls - nrec;
   int n_emits = 0;
   int buf = 0;
-  int n_cached = 0, n_fft = 0, n_redo_cached = 0, n_redo_fft = 0, n_moved = 0;
   bool searched = false; // the registers hold the chain's average (a search has run)
   bool stop_run = false; // the stream ends inside the half-frame a call would emit: no further call in this run
   __syncthreads();
@@ -398,10 +372,8 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
         if (wpos == cache_next_pos) { // (the usual case: no division)
           kq = cache_next_k;
         } else {
-          // (a 64-bit integer division is some hundred instructions, and a chain that a hit has moved off its grid comes
-          // through here at every search: the double-precision quotient with its correction by one instead)
           const int64_t d = wpos - cache_pos;
-          kq = div_floor_pos(d, cache_step);
+          kq = d / cache_step;
           if (kq * cache_step != d) kq = -1;
         }
         if (kq >= 0 && kq < cache_n) {
@@ -411,9 +383,8 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
         }
       }
       if (!cached) strip_load(cap, wpos, w, ln, x);
-      if (redo) (cached ? n_redo_cached : n_redo_fft)++; // diagnostics (lt_batch_cache_stats): added to the run's counters at the end
-      else (cached ? n_cached : n_fft)++;
-      const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo, cached, cache_end);
+      if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached ? 5 : 6) : (cached ? 1 : 2)), 1); // diagnostics
+      const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end);
       searched = true;
       if (redo) {
         redo_k++;
@@ -459,7 +430,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       const int frame_start = peak_pos - kSlotLen;
       peak_pos = kSlotLen;
       const int64_t hf0 = pos + frame_start;
-      if (cache_n > 0 && frame_start != 0) n_moved++; // diagnostics
+      if (cache_n > 0 && frame_start != 0 && tid == 0) atomicAdd(a.slot_next + 4, 1); // diagnostics
       if (hf0 + kHalfFrame > t1) { // (flush only) quirk q1 normalised: never read past the capture
         // (the chain is through for this run -- and must stay so: the second pass of a two-pass run would take the call
         // up again, from an average this search has already gone into)
@@ -489,6 +460,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
     pos = next_pos;
   }
 
+  warm_up_landed(warm);
   // ---- store state
   __syncthreads();
   if (searched && redo_k >= redo_end) strip_ema_store(avg, w, lane, ema); // (else: the average is described as before)
@@ -506,13 +478,6 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
     }
     a.rec_count[chain] = nrec;
     if (stop_run) st->run_done = 1;
-    if (a.cache && a.pass == 1) { // diagnostics
-      if (n_cached) atomicAdd(a.slot_next + 1, n_cached);
-      if (n_fft) atomicAdd(a.slot_next + 2, n_fft);
-      if (n_moved) atomicAdd(a.slot_next + 4, n_moved);
-      if (n_redo_cached) atomicAdd(a.slot_next + 5, n_redo_cached);
-      if (n_redo_fft) atomicAdd(a.slot_next + 6, n_redo_fft);
-    }
   }
 }
 
@@ -709,7 +674,8 @@ __global__ __launch_bounds__(kChainThreads) void lt_find_kernel(const v2f *__res
   int buf = 0;
   fft::c32 x[16];
   strip_load(cap, 0, w, lane, x);
-  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true);
+  WarmUp none;
+  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true, none);
   strip_ema_store(avg, w, lane, ema);
   if (tid == 0) {
     res->peak_pos = r.peak_pos;
