@@ -522,6 +522,38 @@ int64_t lt_batch_record_capacity(int64_t n_samples)
   return (n_samples + history_capacity()) / (LT_HALF_FRAME_LEN - LT_SLOT_LEN) + 2;
 }
 
+namespace {
+// Window cache: room for every chain's windows of a run, up to 16384 slots of 43 KB (705 MB at most; a small batch
+// scans from the cache: its rounds list windows ahead of chains that may leave them early, up to three times what a
+// chain ends up searching).  Allocated by lt_batch_create and by lt_batch_set_window_cache(1 | 2), freed by
+// lt_batch_set_window_cache(0).  Failure is not an error: the batch then runs without a cache.
+void free_window_cache(lt_batch *b)
+{
+  if (b->d_cache) (void)hipFree(b->d_cache);
+  if (b->d_slot_owner) (void)hipFree(b->d_slot_owner);
+  if (b->d_slot_pos) (void)hipFree(b->d_slot_pos);
+  b->d_cache = nullptr;
+  b->d_slot_owner = nullptr;
+  b->d_slot_pos = nullptr;
+  b->cache_slots = 0;
+}
+void alloc_window_cache(lt_batch *b)
+{
+  if (b->d_cache) return;
+  const size_t nchains = (size_t)b->n_channels * 3;
+  const int64_t windows = b->max_samples / LT_HALF_FRAME_LEN + 2;
+  const int64_t per_chain = b->n_channels <= 4 ? 3 * windows + 16 : std::min<int64_t>(windows, lt::cache_max_per_chain());
+  b->cache_slots = (int)std::min<int64_t>((int64_t)nchains * per_chain, 16384);
+  hipError_t ce = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
+  if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
+  if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_pos, (size_t)b->cache_slots * sizeof(int64_t));
+  if (ce != hipSuccess) {
+    (void)hipGetLastError();
+    free_window_cache(b);
+  }
+}
+} // namespace
+
 int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samples,
                     const lt_chain_params *params)
 {
@@ -560,29 +592,7 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMalloc(&b->d_njobs, sizeof(int) * (size_t)lt::scan_counter_ints());
   if (e == hipSuccess) e = hipMalloc(&b->d_parts, (size_t)lt::scan_parts_bytes_per_chain() * nchains);
   if (e == hipSuccess) e = hipMalloc(&b->d_cp, (size_t)lt::per_record_scratch_bytes() * nchains * (size_t)b->rec_cap);
-  {
-    // window cache: room for every chain's windows of a run, up to 16384 of them (43 KB each)
-    // (a small batch scans from the cache: its rounds list windows ahead of chains that may leave them early, up to
-    // three times what a chain ends up searching)
-    const int64_t windows = max_samples / LT_HALF_FRAME_LEN + 2;
-    const int64_t per_chain = n_channels <= 4 ? 3 * windows + 16 : std::min<int64_t>(windows, lt::cache_max_per_chain());
-    b->cache_slots = (int)std::min<int64_t>((int64_t)nchains * per_chain, 16384);
-    if (e == hipSuccess) {
-      // (an accelerator, not a necessity: without the memory for it the per-chain kernel runs in one pass)
-      hipError_t ce = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
-      if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
-      if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_pos, (size_t)b->cache_slots * sizeof(int64_t));
-      if (ce != hipSuccess) {
-        (void)hipGetLastError();
-        if (b->d_cache) (void)hipFree(b->d_cache);
-        if (b->d_slot_owner) (void)hipFree(b->d_slot_owner);
-        b->d_cache = nullptr;
-        b->d_slot_owner = nullptr;
-        b->d_slot_pos = nullptr;
-        b->cache_slots = 0;
-      }
-    }
-  }
+  if (e == hipSuccess) alloc_window_cache(b); // (an accelerator, not a necessity: without the memory for it the per-chain kernel runs in one pass)
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&b->d_hist[i], sizeof(lt_cf32) * (size_t)n_channels * (size_t)b->hist_cap);
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, lt::chain_state_bytes() * nchains);
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
@@ -975,6 +985,12 @@ int lt_batch_cache_stats(lt_batch *b, int64_t stats[7])
 int lt_batch_set_window_cache(lt_batch *b, int on)
 {
   if (!b || on < 0 || on > 2) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0, 1 or 2");
+  HIP_TRY(hipSetDevice(b->device));
+  if ((on == 0) != (b->d_cache == nullptr)) { // the cache's memory goes with level 0 and comes back with 1 / 2
+    if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (on == 0) free_window_cache(b);
+    else alloc_window_cache(b);
+  }
   b->use_cache = on;
   return LT_OK;
 }

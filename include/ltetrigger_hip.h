@@ -182,7 +182,11 @@ int lt_batch_get_mode(lt_batch *b);
  * and the second pass runs general_work on them (a window off the list goes through the transforms there and then).
  * Level 2: in batches of up to four channels -- whose scan rounds are bound by the instruction stream of one root
  * wave per CU, not by the chip -- the rounds' windows are listed too and the scan takes their lag metrics from the cache
- * (no transforms in the round itself).  0 = every search through the transforms.  Same records at every level. */
+ * (no transforms in the round itself).  0 = every search through the transforms.  Same records at every level.
+ * Footprint: min(3 n_channels x windows of max_samples, 16384) slots of 43 008 bytes -- 705 MB at most --, allocated by
+ * lt_batch_create, freed by level 0 and allocated again by 1 / 2 (if the memory cannot be had the batch runs as at level 0).
+ * A level-2 run that needs more than the slots there are (a capture of several seconds on up to four channels) takes its
+ * later rounds' searches through the transforms. */
 int lt_batch_set_window_cache(lt_batch *b, int level);
 /* Diagnostics of the last run: stats[0] = windows asked for, [1] = searches of the second pass served from the cache,
  * [2] = searches of the second pass that went through the transforms, [3] = chains that waited for the cache,
