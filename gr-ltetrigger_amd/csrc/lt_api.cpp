@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -156,7 +157,7 @@ struct lt_batch {
   void *d_slot_owner = nullptr;
   void *d_slot_pos = nullptr;
   int cache_slots = 0;
-  int use_cache = 2;         // lt_batch_set_window_cache
+  int use_cache = 3;         // lt_batch_set_window_cache (3 = 2 with the per-chain kernel's second pass on demand)
   void *d_cp = nullptr;      // per-record scratch (CP metrics, work list), [n_channels*3][rec_cap] x per_record_scratch_bytes()
   lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
   int hist_sel = 0;
@@ -193,6 +194,12 @@ struct lt_batch {
   int *cur_count = nullptr;
   uint64_t set_run[2] = {0, 0};    // 1 + the number of the run whose records set 0 / 1 holds (0: none)
   hipStream_t copy = nullptr;      // lt_batch_collect_previous: its copies, beside the run in flight
+  // Two passes of the per-chain kernel (around lt_metric_kernel) only while chains want the window cache: the kernel writes
+  // the number of the last run in which one did, and of the last run it ran in, into two words of pinned host memory; a
+  // run launched when the latest run known in full had no such chain launches the kernel once, without the cache (two
+  // launches fewer: 10 us of a 64-channel step).  Timing only: the records are the same either way.
+  int *h_wait_hint = nullptr;
+  int *d_wait_hint = nullptr;
 };
 
 struct lt_decim {
@@ -598,6 +605,17 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
   if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(int) * nchains);
   for (int i = 0; i < lt_batch::kPhaseRing && e == hipSuccess; ++i)
     for (int j = 0; j < 4 && e == hipSuccess; ++j) e = hipEventCreate(&b->ev[i][j]);
+  if (e == hipSuccess) { // (a convenience: without the word every run has its two passes)
+    if (hipHostMalloc(reinterpret_cast<void **>(&b->h_wait_hint), 2 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_wait_hint), b->h_wait_hint, 0) == hipSuccess) {
+      b->h_wait_hint[0] = b->h_wait_hint[1] = 0;
+    } else {
+      (void)hipGetLastError();
+      if (b->h_wait_hint) (void)hipHostFree(b->h_wait_hint);
+      b->h_wait_hint = nullptr;
+      b->d_wait_hint = nullptr;
+    }
+  }
   b->ev0 = b->ev[0][0];
   b->ev1 = b->ev[0][3];
   b->cur_recs = b->d_recs;
@@ -626,6 +644,7 @@ void lt_batch_free(lt_batch *b)
       if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : b->rec_done)
     if (e) (void)hipEventDestroy(e);
+  if (b->h_wait_hint) (void)hipHostFree(b->h_wait_hint);
   if (b->copy) (void)hipStreamDestroy(b->copy);
   if (b->side) (void)hipStreamDestroy(b->side);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -753,11 +772,24 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.n_cus = b->n_cus;
   R.cp_scratch = b->d_cp;
   R.cache = b->use_cache ? b->d_cache : nullptr;
-  R.cache_level = b->use_cache;
+  R.cache_level = b->use_cache > 2 ? 2 : b->use_cache;
   R.slot_owner = b->d_slot_owner;
   R.slot_pos = b->d_slot_pos;
   R.slot_cap = b->cache_slots;
   R.records_delay_us = b->records_delay_us;
+  R.wait_hint = b->d_wait_hint;
+  R.run_id = (int)((b->n_runs + 1) & 0x3fffffff);
+  // h_wait_hint[0] = the last run in which a chain asked, [1] = the last run whose per-chain kernel is known to have run:
+  // everything up to run [1] - 1 is through (stream order), so "nobody asked in the latest run known in full" is
+  // [0] <= [1] - 2.  The host may be any number of runs ahead of the device; until it knows of a run, two passes.
+  {
+    const int asked = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[0] : 0;
+    const int done = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[1] : 0;
+    // level 3 (the default): one pass until a chain has asked, then two passes while chains keep asking; levels 1 and 2:
+    // two passes always
+    R.two_pass = b->use_cache != 3 || !b->h_wait_hint || (asked > 0 && asked > done - 2);
+    if (b->n_runs == 0x3fffffff && b->h_wait_hint) b->h_wait_hint[0] = b->h_wait_hint[1] = 0; // (the run numbers wrap)
+  }
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
   // (an event between two launches costs the stream ~5 us: the stage events are there for lt_batch_phase_ms only --
   // and the one behind the per-chain kernel for the per-record kernels' stream in overlap mode)
@@ -984,7 +1016,7 @@ int lt_batch_cache_stats(lt_batch *b, int64_t stats[7])
 
 int lt_batch_set_window_cache(lt_batch *b, int on)
 {
-  if (!b || on < 0 || on > 2) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0, 1 or 2");
+  if (!b || on < 0 || on > 3) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0, 1, 2 or 3");
   HIP_TRY(hipSetDevice(b->device));
   if ((on == 0) != (b->d_cache == nullptr)) { // the cache's memory goes with level 0 and comes back with 1 / 2
     if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));

@@ -55,6 +55,9 @@ struct ChainArgs {
   int *launch_slots;   // ... those of them that pass 0 hands out (lt_metric_kernel's share of the work)
   int slot_cap;
   int pass;
+  int *wait_hint;      // two words of pinned host memory (or null): [0] set to run_id by a chain that has enough searches ahead
+  int run_id;          // of it to ask for the cache -- whether the run has one or not --, [1] by the kernel as such (pass 0):
+                       // the host's cue to give the next runs two passes or one
 };
 constexpr int kCacheStripLags = 64 * kStripRegs;   // 896 floats per (slot, strip)
 constexpr int kCacheMinSearches = 6;               // fewer searches ahead than this: not worth a pass of its own
@@ -236,13 +239,14 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
   // everything to pass 1.  An idle or acquiring chain searches every window from pos on; a tracked one every
   // (track_every + 1)-th from its next search on.  (Windows its average still has to be run through -- pre_n -- are
   // found in the cache if they lie on the same grid, and go through the transforms if not.)
-  if (a.cache && a.pass == 0 && can_call(pos) && nrec < a.rec_cap) {
+  if ((a.cache || a.wait_hint) && a.pass == 0 && can_call(pos) && nrec < a.rec_cap) {
     const int stride = st->is_tracking ? a.track_every + 1 : 1;
     const int64_t first = pos + (st->is_tracking ? (int64_t)st->timer * kHalfFrame : 0);
     const int64_t last_start = a.flush ? t1 - kHalfFrame : t1 - kCallReach; // last position a call may start at
     int64_t ahead = first <= last_start ? (last_start - first) / ((int64_t)stride * kHalfFrame) + 1 : 0;
     if (ahead > kCacheMaxPerChain) ahead = kCacheMaxPerChain;
-    if (ahead >= kCacheMinSearches) {
+    if (ahead >= kCacheMinSearches && a.wait_hint && tid == 0) *reinterpret_cast<volatile int *>(a.wait_hint) = a.run_id;
+    if (a.cache && ahead >= kCacheMinSearches) {
       __shared__ int s_base;
       if (tid == 0) s_base = atomicAdd(a.slot_next, (int)ahead);
       __syncthreads();
@@ -489,6 +493,8 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
 __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
 {
   chain_run(a);
+  // (the host's cue, lt_api.cpp: this run's per-chain kernel has run -- so every launch of the run before is through)
+  if (a.pass == 0 && a.wait_hint && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(a.wait_hint)[1] = a.run_id;
   __threadfence_block();
   __syncthreads();
   const int chain = blockIdx.x, tid = threadIdx.x, lane = tid & 63;

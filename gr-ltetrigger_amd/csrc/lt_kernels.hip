@@ -118,11 +118,21 @@ __global__ __launch_bounds__(128) void lt_sss_m0m1_kernel(const v2f *__restrict_
 // Algorithmic bytes: 8 B in + 8/D B out per input sample; arithmetic: 2 NTAPS / D FMAs per input sample.
 //
 // lt_decim_generic_kernel: any other rate, one thread per output, same arithmetic.
-constexpr int kDecimThreads = 256; // (128 and 512 measured: 3 % and 15 % slower)
-constexpr int kDecimPhases = 32;
-constexpr int kDecimRow = kDecimThreads + 17; // row length in samples: >= threads + lead / 32, = 1 mod 16
+#ifndef LT_DECIM_P
+#define LT_DECIM_P 32
+#endif
+constexpr int kDecimPhases = LT_DECIM_P;
+constexpr int kDecimThreads = 8192 / kDecimPhases; // 32 phases x 256 threads (128 and 512 measured: 3 % and 15 % slower)
+constexpr int kDecimGeneric = 256;
 
 __host__ __device__ constexpr int decim_lead(int ntaps) { return ((ntaps - 1 + kDecimPhases - 1) / kDecimPhases) * kDecimPhases; }
+// row length in samples: >= threads + lead / phases, = 1 mod 16
+__host__ __device__ constexpr int decim_row(int ntaps)
+{
+  int r = kDecimThreads + decim_lead(ntaps) / kDecimPhases;
+  while (r % 16 != 1) ++r;
+  return r;
+}
 
 __device__ __forceinline__ v2f fma_tap(float t, v2f x, v2f acc)
 {
@@ -134,8 +144,8 @@ template <int kD, int kNtaps>
 __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
                                                                     int64_t n_in, int64_t n_out, const float *__restrict__ tt)
 {
-  constexpr int P = kDecimPhases, B = P / kD, T = kDecimThreads, R = kDecimRow;
-  static_assert(P % kD == 0 && B >= 1, "the decimation must divide the 32 phases");
+  constexpr int P = kDecimPhases, B = P / kD, T = kDecimThreads, R = decim_row(kNtaps);
+  static_assert(P % kD == 0 && B >= 1 && (P & (P - 1)) == 0, "the decimation must divide the phases");
   constexpr int lead = decim_lead(kNtaps);
   constexpr int span = P * T + lead;
   static_assert(T + lead / P <= R, "row too short");
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
     const v2f *bp = x + (int64_t)c * n_in + base_i;
     const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(bp), 0, (int)avail * (int)sizeof(v2f), 0x00020000);
     const int shift = (int)(first - base_i); // <= 0: offsets of samples in front of the stream wrap to huge unsigned values
-    const int row = tid & (P - 1), col0 = tid >> 5;
+    const int row = tid & (P - 1), col0 = tid / P;
     v2f *dst = xs + row * R + col0;
     constexpr int n_it = (span + T - 1) / T;
     constexpr int kBatch = n_it; // all of a thread's loads in flight together: one memory round trip per block
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
   // takes it with tap j = n + (b - (B - 1)) D.  The steps run in units of U = D (32 taps each: two scalar loads of 16
   // from the table `tt`, laid out [unit][step][output] by decim_tap_table below); a unit's LDS reads and taps are fetched
   // while the unit before it computes.  Everything is unrolled: which (step, output) pairs have a tap is known here.
-  constexpr int U = kD, G = P / U; // G units per chunk of 32 steps (G = B: even, so a unit's buffer is its index's parity)
+  constexpr int U = 32 / B, G = P / U; // G units per chunk of P steps (even, so a unit's buffer is its index's parity)
   static_assert(U * B == 32 && G % 2 == 0, "a unit is 32 taps; the two buffers alternate in step with the chunks");
   constexpr int m_last = (n_steps - 1) / P; // chunks 0 and m_last have (step, output) pairs without a tap: unrolled apart
   static_assert(m_last >= 2 && P * (m_last - 1) + P - 1 <= kNtaps - 1 && P * 1 - (B - 1) * kD >= 0, "the steady chunks must lie inside the taps");
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
     _Pragma("unroll") for (int u = 0; u < U; ++u)                                                        \
     {                                                                                                    \
       const int r = (g) * U + u;                                                                         \
-      if (!kPeel || P * (m) + r < n_steps) xv[(g) & 1][u] = xl[((W0 - r) & (P - 1)) * R + ((W0 - r) >> 5) - (m)]; \
+      if (!kPeel || P * (m) + r < n_steps) xv[(g) & 1][u] = xl[((W0 - r) & (P - 1)) * R + ((W0 - r) / P) - (m)]; \
     }                                                                                                    \
     const float *tp = tt + ((m) * G + (g)) * 32;                                                         \
     _Pragma("unroll") for (int i = 0; i < 32; ++i) tv[(g) & 1][i] = tp[i];                               \
@@ -243,12 +253,12 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
 
 // any decimation: one thread per output, samples from global memory (the taps walk down the stream: a lane's reads
 // are consecutive and stay in its cache lines)
-__global__ __launch_bounds__(kDecimThreads) void lt_decim_generic_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
+__global__ __launch_bounds__(kDecimGeneric) void lt_decim_generic_kernel(const v2f *__restrict__ x, v2f *__restrict__ y,
                                                                          int64_t n_in, int64_t n_out, int D,
                                                                          const float *__restrict__ taps, int ntaps)
 {
   const int c = blockIdx.y;
-  const int64_t k = (int64_t)blockIdx.x * kDecimThreads + threadIdx.x;
+  const int64_t k = (int64_t)blockIdx.x * kDecimGeneric + threadIdx.x;
   if (k >= n_out) return;
   const v2f *xc = x + (int64_t)c * n_in;
   v2f acc = {0.f, 0.f};
@@ -755,7 +765,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.launch_slots = R.n_jobs + kCtrLaunchSlots + n_metric_launches;
     c.slot_cap = R.slot_cap;
     c.pass = 0;
-    if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && R.cache_level >= 1)) c.cache = nullptr;
+    c.wait_hint = R.wait_hint;
+    c.run_id = R.run_id;
+    if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && R.cache_level >= 1 && R.two_pass)) c.cache = nullptr;
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     if (c.cache) {
       // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
@@ -877,16 +889,16 @@ hipError_t launch_sss_m0m1(const void *sym, const DeviceTables *tab, int n_id_2,
   return hipGetLastError();
 }
 
-// The taps in the order lt_decim_kernel<D, NTAPS> walks them: [unit q][step u < D][output b < 32 / D] = taps[j],
-// j = q D + u + (b - (B - 1)) D (0 where the pair has no tap: never used).
+// The taps in the order lt_decim_kernel<D, NTAPS> walks them: [unit q][step u < U][output b < B] = taps[j],
+// B = phases / D, U = 32 / B, j = q U + u + (b - (B - 1)) D (0 where the pair has no tap: never used).
 std::vector<float> decim_tap_table(int D, const float *taps, int ntaps)
 {
-  const int B = kDecimPhases / D, n_steps = ntaps + (B - 1) * D, Q = (n_steps + D - 1) / D;
+  const int B = kDecimPhases / D, U = 32 / B, n_steps = ntaps + (B - 1) * D, Q = (n_steps + U - 1) / U;
   std::vector<float> t((size_t)Q * 32, 0.f);
   for (int q = 0; q < Q; ++q)
-    for (int u = 0; u < D; ++u)
+    for (int u = 0; u < U; ++u)
       for (int b = 0; b < B; ++b) {
-        const int j = q * D + u + (b - (B - 1)) * D;
+        const int j = q * U + u + (b - (B - 1)) * D;
         if (j >= 0 && j < ntaps) t[(size_t)q * 32 + u * B + b] = taps[j];
       }
   return t;
@@ -918,8 +930,8 @@ hipError_t launch_decim(const void *x, void *y, int n_channels, int64_t n_in, in
     }
   }
   if (n_channels > 65535) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)((n_out + kDecimThreads - 1) / kDecimThreads), (unsigned)n_channels);
-  hipLaunchKernelGGL(lt_decim_generic_kernel, grid, dim3(kDecimThreads), 0, stream, xi, yo, n_in, n_out, D, taps, ntaps);
+  const dim3 grid((unsigned)((n_out + kDecimGeneric - 1) / kDecimGeneric), (unsigned)n_channels);
+  hipLaunchKernelGGL(lt_decim_generic_kernel, grid, dim3(kDecimGeneric), 0, stream, xi, yo, n_in, n_out, D, taps, ntaps);
   return hipGetLastError();
 }
 

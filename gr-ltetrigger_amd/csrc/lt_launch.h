@@ -55,6 +55,11 @@ struct RunLaunch {
   int cache_level = 2;        // 0 = no cache, 1 = the per-chain kernel's two passes, 2 = also the scan rounds of small batches
   int slot_cap = 0;
   int records_delay_us = 0;   // diagnostics (lt_batch_debug_hold_records): the per-record kernels start this much later
+  int *wait_hint = nullptr;   // device view of two words in pinned host memory: the number of the last run in which a chain had
+                              // enough searches ahead of it to ask for the window cache, and of the last run the per-chain kernel ran in
+  int run_id = 0;             // this run's number (from 1)
+  int two_pass = 1;           // 0: the per-chain kernel in one pass without the cache (no lt_metric_kernel, no second launch):
+                              // no chain asked in the latest run the caller knows in full.  Timing only, never a record
   int list_slot = 0;          // which of the two work lists (and of their counters behind the job counters) this run uses (0 / 1)
 };
 

@@ -660,7 +660,11 @@ __global__ __launch_bounds__(256) void lt_plan_kernel(PlanArgs a)
       if (i != a.keep_counter) a.n_jobs[i] = 0;
     if (a.rebase)
       for (int i = threadIdx.x; i < a.n_channels * 3; i += 256) a.state[i].pos = 0;
-    __threadfence();
+    // (one workgroup: what it has just stored is read back -- by other threads, and through atomics that execute in the
+    // L2 -- by this CU only, whose L1 held none of those lines when the kernel started: the stores have to be in the L2,
+    // which is what a workgroup-scope fence waits for.  The agent-scope fence that stood here also wrote the XCD's L2
+    // back and invalidated it: 3 us of the run's first launch.)
+    __threadfence_block();
     __syncthreads();
   }
   __shared__ ScanJob *planned[256];

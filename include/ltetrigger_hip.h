@@ -176,13 +176,18 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
-/* Window cache (default 2).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
+/* Window cache (default 3).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
  * cell, every chain in mode 0 -- the per-chain kernel takes in two passes: the first lists the windows every such chain
  * has ahead of it on its present timing, lt_metric_kernel forms their lag metrics for all chains at once, chip-wide,
  * and the second pass runs general_work on them (a window off the list goes through the transforms there and then).
  * Level 2: in batches of up to four channels -- whose scan rounds are bound by the instruction stream of one root
  * wave per CU, not by the chip -- the rounds' windows are listed too and the scan takes their lag metrics from the cache
- * (no transforms in the round itself).  0 = every search through the transforms.  Same records at every level.
+ * (no transforms in the round itself).  Level 3 = level 2, with the per-chain kernel's two passes (and lt_metric_kernel
+ * between them) launched only while chains ask for the cache: the kernel tells the host, through two words of pinned memory,
+ * in which run a chain last had enough searches ahead of it to ask; a run enqueued when the latest run the host knows in
+ * full had none -- and every run before the first such report -- launches the kernel once, without the cache (two launches
+ * fewer per run; a capture that turns marginal pays its first runs' searches through the transforms until the report is in).
+ * 0 = every search through the transforms.  Same records at every level.
  * Footprint: min(3 n_channels x windows of max_samples, 16384) slots of 43 008 bytes -- 705 MB at most --, allocated by
  * lt_batch_create, freed by level 0 and allocated again by 1 / 2 (if the memory cannot be had the batch runs as at level 0).
  * A level-2 run that needs more than the slots there are (a capture of several seconds on up to four channels) takes its

@@ -587,7 +587,22 @@ def test_window_cache_gives_the_same_records(lt, oracle, frames_192, mode):
     want = oracle.batch_run(iq, nthreads=8)
     for c in range(18):
         assert_records_match(out[1][c], want[c], f"chain {c}")
-    # a small batch (up to four channels) at level 2, the default: the scan rounds themselves take their lag metrics
+    # level 3, the default: the per-chain kernel runs once, without the cache, until a chain has had enough searches ahead of
+    # it to ask (the kernel reports the run through pinned host memory), and in two passes while chains keep asking -- the
+    # first run of a fresh batch is one pass, the runs after a collect (the host has seen the report) two; same records
+    b = lt.Batch(6, iq.shape[1])
+    b.set_mode(mode)
+    seen = []
+    for k in range(3):
+        b.reset()
+        b.run_host(iq)
+        got = b.collect()
+        for c in range(18):
+            assert got[c].tobytes() == out[0][c].tobytes(), f"level 3 run {k} chain {c}"
+        seen.append(b.cache_stats())
+    assert seen[0][1] == 0 and seen[0][3] == 0, f"a fresh batch's first run has one pass: {seen[0]}"
+    assert seen[1][3] > 0 and seen[1][1] > 50 and seen[2][1] > 50, f"two passes once chains have asked: {seen[1:]}"
+    # a small batch (up to four channels) at level 2: the scan rounds themselves take their lag metrics
     # from the cache -- the first three channels' records are those they have in the batch of six
     if mode == 1:
         for level in (2, 1):
@@ -612,7 +627,7 @@ def test_stream_ending_inside_an_emission_ends_the_run_in_both_passes(lt, oracle
     iq, kw = siggen.random_scene(seed, frames_192, list(FIXTURES), lo, hi, snr)
     want = oracle.batch_run(iq, nthreads=8, **kw)
     for mode in (1, 0):
-        for level in (2, 1, 0):
+        for level in (3, 2, 1, 0):
             b = lt.Batch(iq.shape[0], iq.shape[1], **kw)
             b.set_mode(mode)
             b.set_window_cache(level)

@@ -226,7 +226,7 @@ def main():
             b.close()
             r = np.random.default_rng(seed * 13 + 5)
             for k in range(args.variants):
-                v = {"mode": int(r.integers(0, 2)), "cache": int(r.integers(0, 3)), "groups": int(r.integers(0, 4)),
+                v = {"mode": int(r.integers(0, 2)), "cache": int(r.integers(0, 4)), "groups": int(r.integers(0, 4)),
                      "segments": [None, (1, 5), (2, 32), (64, 64), (3, 128), (1, 1)][int(r.integers(0, 6))]}
                 b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
                 b.set_mode(v["mode"])
