@@ -574,18 +574,26 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     __syncthreads();
     // ---- d_cfo_data ring, mean_cfo() (lib/pss_impl.cc:94-109,200-204): in call order, one wave
     if (w == 0 && (n_ran > 0 || t_lost)) {
+      // (the lane index made opaque: otherwise the compiler forms the ring's lane-dependent addresses in HBM at the top of the
+      // kernel's tail and spills them across the CFO loop)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
       if (!ring_open) {
-        cfo_ring_begin(st, t_ring, ring, lane);
+        cfo_ring_begin(st, t_ring, ring, ln);
         ring_open = true;
       }
       const int nb = count - b0 < kChainThreads ? count - b0 : kChainThreads;
-      cfo_ring_records(t_ring, ring, nb, lane,
+      cfo_ring_records(t_ring, ring, nb, ln,
                        [&](int k, uint32_t &f, float &c) { f = t_flags[k]; c = t_cfo[k]; },
                        [&](int k, float mean) { recs[b0 + k].mean_cfo = mean; });
     }
     __syncthreads();
   }
-  if (w == 0 && ring_open) cfo_ring_end(st, t_ring, ring, lane);
+  if (w == 0 && ring_open) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    cfo_ring_end(st, t_ring, ring, ln);
+  }
 }
 
 // ---------------------------------------------------------------- window cache: the lag metric in bulk
