@@ -598,7 +598,6 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
   ScanJob *jobs = reinterpret_cast<ScanJob *>(R.jobs);
   StripPartial *parts = reinterpret_cast<StripPartial *>(R.parts);
   const int64_t t1 = R.t0 + R.n;
-  int n_metric_launches = 0; // lt_metric_kernel launches of the scan rounds (each has its count of slots: launch_slots)
   // ---- rounds of plan, scan, resolve.  An idle chain needs one round per `seg_len` windows; a chain that fires
   // needs a few more (a round ends for it where it re-aligns, where tracking starts, where it is lost).  Rounds
   // with nothing left to do cost three empty launches; whatever a chain has not got through after the last one --
@@ -678,7 +677,6 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     mm.hist_len = R.hist_len; mm.slot_owner = p.slot_owner; mm.slot_pos = p.slot_pos; mm.launch_slots = R.n_jobs + kCtrLaunchSlots;
     mm.slot_cap = R.slot_cap; mm.cache = reinterpret_cast<float *>(R.cache); mm.tab = R.tab;
     const int metric_grid = 4 * (R.n_cus > 0 ? R.n_cus : 256);
-    n_metric_launches = 0;
     hipLaunchKernelGGL(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
       s.jobs = q.jobs = jobs2[r & 1];
@@ -690,11 +688,11 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       q.next.jobs = jobs2[(r + 1) & 1];
       q.next.n_jobs = R.n_jobs + 2 * (r + 1);
       q.next.round_slots = R.n_jobs + kCtrLaunchSlots + (r + 1);
-      if (cached_scan) { // the lag metrics of this round's windows, before its scan
-        mm.n_before = r;
+      if (cached_scan) { // the lag metrics of this round's windows, before its scan (the round's slots: from 0)
+        mm.n_before = 0;
+        mm.launch_slots = R.n_jobs + kCtrLaunchSlots + r;
         hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)metric_grid), dim3(64 * kMetricWaves), 0, stream, mm);
       }
-      n_metric_launches = cached_scan ? r + 1 : 0;
       if (G == 1) hipLaunchKernelGGL(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
       else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
       else hipLaunchKernelGGL(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
@@ -762,7 +760,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.slot_owner = reinterpret_cast<int2 *>(R.slot_owner);
     c.slot_pos = reinterpret_cast<int64_t *>(R.slot_pos);
     c.slot_next = R.n_jobs + kCtrSlots; // (cleared with the run's other counters by its first launch)
-    c.launch_slots = R.n_jobs + kCtrLaunchSlots + n_metric_launches;
+    c.launch_slots = R.n_jobs + kCtrLaunchSlots + kMaxRounds + 1; // (its own count: the rounds are over, their slots free)
     c.slot_cap = R.slot_cap;
     c.pass = 0;
     c.wait_hint = R.wait_hint;
@@ -773,8 +771,8 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
       MetricArgs m;
       m.iq = iq; m.ch_stride = R.ch_stride; m.hist = hist; m.hist_stride = R.hist_stride; m.t0 = R.t0; m.n = R.n;
-      m.hist_len = R.hist_len; m.slot_owner = c.slot_owner; m.slot_pos = c.slot_pos; m.launch_slots = R.n_jobs + kCtrLaunchSlots;
-      m.n_before = n_metric_launches; m.slot_cap = c.slot_cap;
+      m.hist_len = R.hist_len; m.slot_owner = c.slot_owner; m.slot_pos = c.slot_pos; m.launch_slots = c.launch_slots;
+      m.n_before = 0; m.slot_cap = c.slot_cap;
       m.cache = c.cache; m.tab = R.tab;
       const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
       hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);

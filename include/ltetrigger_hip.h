@@ -190,8 +190,8 @@ int lt_batch_get_mode(lt_batch *b);
  * 0 = every search through the transforms.  Same records at every level.
  * Footprint: min(3 n_channels x windows of max_samples, 16384) slots of 43 008 bytes -- 705 MB at most --, allocated by
  * lt_batch_create, freed by level 0 and allocated again by 1 / 2 (if the memory cannot be had the batch runs as at level 0).
- * A level-2 run that needs more than the slots there are (a capture of several seconds on up to four channels) takes its
- * later rounds' searches through the transforms. */
+ * The slots of a scan round (levels 2 / 3, up to four channels) are free again after the round: a capture of any length
+ * scans from the cache. */
 int lt_batch_set_window_cache(lt_batch *b, int level);
 /* Diagnostics of the last run: stats[0] = windows asked for, [1] = searches of the second pass served from the cache,
  * [2] = searches of the second pass that went through the transforms, [3] = chains that waited for the cache,
