@@ -142,3 +142,29 @@ def test_chain_end_of_stream_rules(oracle):
     assert len(oracle.chain_run(x[:9600], 0)) == 1
     r = oracle.chain_run(np.zeros(0, np.complex64), 0)
     assert len(r) == 0
+
+
+def test_first_cell_of_a_channel_is_the_fixture_cell(oracle):
+    """bench.py's `config5` leg decides "detected" with first_cell(): every chain's mib stage walks its emitted half-frames
+    in call order, the first successful PBCH decode publishes, the channel's first `track` is the one earliest in the
+    stream (lib/mib_impl.cc:97-183 with exit_on_success).  On the oracle's records of a bundled frame that is the frame's
+    own cell -- and nothing when the threshold keeps every chain from tracking."""
+    import bench
+    from oracle import mib_oracle as M
+    x, _, expect = load_frame("6prb")
+    iq = np.tile(x, 40)
+
+    def hf_of(recs_src):
+        def hf(r):
+            p0 = int(r["out_pos"])
+            out = np.zeros(oracle.HALF_FRAME, np.complex64)
+            lo, hi = max(p0, 0), min(p0 + oracle.HALF_FRAME, iq.size)
+            out[lo - p0:hi - p0] = iq[lo:hi]
+            return oracle.cfo_correct(out, float(np.float32(-r["mean_cfo"]) / np.float32(128)))
+        return hf
+
+    recs = oracle.batch_run(iq[None, :], nthreads=3)
+    cell = bench.first_cell(recs[0:3], hf_of(recs), M.decode_mib, oracle)
+    assert cell == (expect["cell_id"], expect["nof_prb"], 1)
+    quiet = oracle.batch_run(iq[None, :], psr_threshold=1e9, nthreads=3)
+    assert bench.first_cell(quiet[0:3], hf_of(quiet), M.decode_mib, oracle) is None
