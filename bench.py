@@ -151,8 +151,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (SNR sweep at 30.72 Msps)")
     ap.add_argument("--config5-trials", type=int, default=50, help="seeded trials per SNR point of the config5 leg")
     ap.add_argument("--config5-snrs", default="", help="comma-separated SNRs in dB (default -10..10 in steps of 2)")
+    ap.add_argument("--config5-window-cache", type=int, default=4,
+                    help="lt_batch_set_window_cache level of the config5 leg (4 = lag-metric streams; the default level's time is reported beside it)")
     ap.add_argument("--config5-seconds", type=float, default=1.0, help="capture length per trial of the config5 leg")
     ap.add_argument("--mode", type=int, default=1, help="lt_batch_set_mode (1 = grid scan + per-chain kernel)")
+    ap.add_argument("--window-cache", type=int, default=-1, help="lt_batch_set_window_cache level (default: the library's)")
     ap.add_argument("--overlap", action="store_true",
                     help="time the steps with lt_batch_set_overlap(1): a step's per-record kernels on a second stream beside the "
                          "next step's scan rounds (default: off, the library's default; the bench line carries that "
@@ -233,6 +236,8 @@ def main():
     # what follows the input's generation is the warm-up)
     batch = lt.Batch(n_ch, n, psr_threshold=4.0, device=local_rank)
     batch.set_mode(args.mode)
+    if args.window_cache >= 0:
+        batch.set_window_cache(args.window_cache)
     batch.set_overlap(args.overlap)
     if args.scan_segments:
         batch.set_scan_segments(*[int(v) for v in args.scan_segments.split(",")])
@@ -500,7 +505,8 @@ def main():
             out["config2"] = config2(torch, lt, dev, local_rank)
         if world == 1 and not args.no_config5:
             snrs = [float(v) for v in args.config5_snrs.split(",")] if args.config5_snrs else list(range(-10, 11, 2))
-            out["config5"] = config5(torch, lt, dev, local_rank, snrs, args.config5_trials, args.config5_seconds, args.cpu_threads)
+            out["config5"] = config5(torch, lt, dev, local_rank, snrs, args.config5_trials, args.config5_seconds, args.cpu_threads,
+                                     args.config5_window_cache)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lt, iq, recs, min(args.cpu_channels, n_ch), value / world, args.cpu_threads)
         print(json.dumps(out), flush=True)
@@ -639,7 +645,7 @@ def first_cell(recs3, halfframe, decode, F):
     return None if best is None else best[2]
 
 
-def config5(torch, lt, dev, device, snrs, trials, seconds, threads=0):
+def config5(torch, lt, dev, device, snrs, trials, seconds, threads=0, window_cache=4):
     """BASELINE configs[4] in full: the 100-PRB fixture looped to `seconds` at 30.72 Msps + AWGN, SNR as in
     examples/snr_ltetrigger.grc:612-663 (mean signal power over mean noise power across the full sampled band, both
     before the sum), `trials` seeded host-drawn noise realisations (numpy PCG64: the same samples on every box; trial t's
@@ -683,18 +689,27 @@ def config5(torch, lt, dev, device, snrs, trials, seconds, threads=0):
     for snr in snrs:
         torch.add(sig[None, :], noise, alpha=float(np.sqrt(p_sig / (10.0 ** (snr / 10.0)) / 2.0)), out=mixed)
         torch.cuda.synchronize()
-        ms, dms = [], []
-        for rep in range(3):  # the first pass warms caches and clocks; the median of the three is reported
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            bt.batch.reset()
-            e0.record(s)
-            dec.run_device(mr.data_ptr(), yr.data_ptr(), T, n_in, s.cuda_stream)
-            e1.record(s)
-            bt.batch.run_device(yr.data_ptr(), n_out, s.cuda_stream)
-            e2.record(s)
-            torch.cuda.synchronize()
-            dms.append(e0.elapsed_time(e1))
-            ms.append(e0.elapsed_time(e2))
+        ms, dms, ms_other = [], [], []
+        # (the library's default level first -- timing only --, then the level of this leg: its records are the ones compared)
+        for level in ([3, window_cache] if window_cache != 3 else [3]):
+            bt.batch.set_window_cache(level)
+            ms_l, dms_l = [], []
+            for rep in range(3):  # the first pass warms caches and clocks; the median of the three is reported
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                bt.batch.reset()
+                e0.record(s)
+                dec.run_device(mr.data_ptr(), yr.data_ptr(), T, n_in, s.cuda_stream)
+                e1.record(s)
+                bt.batch.run_device(yr.data_ptr(), n_out, s.cuda_stream)
+                e2.record(s)
+                torch.cuda.synchronize()
+                dms_l.append(e0.elapsed_time(e1))
+                ms_l.append(e0.elapsed_time(e2))
+                bt.batch.collect()  # (the host's cue for the next run: one pass or two, lt_batch_set_window_cache 3 / 4)
+            if level == window_cache:
+                ms, dms = ms_l, dms_l
+            else:
+                ms_other = ms_l
         recs = bt.batch.collect()
         stats = bt.batch.cache_stats()
         # ---- the product's detection: MIB replay on the host over the records
@@ -737,6 +752,7 @@ def config5(torch, lt, dev, device, snrs, trials, seconds, threads=0):
                  "gpu_wrong_cell": sum(c is not None and c != target for c in gpu_cells),
                  "trial_for_trial_equal": gpu_cells == cpu_cells, "records_equal": same, "arg_max_ties": ties,
                  "ms": round(float(np.median(ms)), 4), "decimator_ms": round(float(np.median(dms)), 4),
+                 "ms_level3": round(float(np.median(ms_other)), 4) if ms_other else None,
                  "cpu_oracle_s": round(cpu_s, 3), "searches_cached": stats[1], "searches_transformed": stats[2], "moved_off_grid": stats[4]}
         points.append(point)
         all_trials = all_trials and point["trial_for_trial_equal"]
@@ -757,7 +773,12 @@ def config5(torch, lt, dev, device, snrs, trials, seconds, threads=0):
         "cpu_rate": [round(p["cpu_detected"] / T, 3) for p in points],
         "gpu_wrong_cell": [p["gpu_wrong_cell"] for p in points],
         "trial_for_trial_equal": bool(all_trials), "records_equal": bool(all_records), "arg_max_ties": ties_total,
-        "ms_per_point": ms_pts, "decimator_ms_per_point": [p["decimator_ms"] for p in points],
+        "window_cache": window_cache,
+        "window_cache_note": "lt_batch_set_window_cache level of this leg.  4 = the per-chain kernel's searches out of the chains' "
+                             "lag-metric streams (made for marginal SNR, where every hit moves a chain's grid; same records as the "
+                             "oracle's -- this leg checks it -- but not the bits of levels 0..3: tests/test_gpu_stream.py).  The "
+                             "library's default is 3; its time per point is ms_per_point_level3",
+        "ms_per_point": ms_pts, "ms_per_point_level3": [p["ms_level3"] for p in points], "decimator_ms_per_point": [p["decimator_ms"] for p in points],
         "path_ms_per_point": [round(p["ms"] - p["decimator_ms"], 4) for p in points],
         "searches_cached": [p["searches_cached"] for p in points],
         "searches_transformed": [p["searches_transformed"] for p in points],

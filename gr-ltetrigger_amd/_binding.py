@@ -346,8 +346,9 @@ class Batch:
 
     def set_window_cache(self, level):
         """Lag metrics formed in bulk: 0 = never, 1 = for the per-chain kernel, 2 = also for the scan rounds of small
-        batches, 3 (default) = 2 with the per-chain kernel's second pass only while chains ask for it
-        (lt_batch_set_window_cache)."""
+        batches, 3 (default) = 2 with the per-chain kernel's second pass only while chains ask for it, 4 = 3 with the
+        lag-metric streams of the chains that are not tracking (searches on any timing served from the cache: marginal
+        SNR; the oracle's records, but not the bits of levels 0..3) (lt_batch_set_window_cache)."""
         _check(lib().lt_batch_set_window_cache(self._h, int(level)), "lt_batch_set_window_cache")
 
     def cache_stats(self):

@@ -773,6 +773,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.cp_scratch = b->d_cp;
   R.cache = b->use_cache ? b->d_cache : nullptr;
   R.cache_level = b->use_cache > 2 ? 2 : b->use_cache;
+  R.stream = b->use_cache == 4;
   R.slot_owner = b->d_slot_owner;
   R.slot_pos = b->d_slot_pos;
   R.slot_cap = b->cache_slots;
@@ -787,7 +788,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
     const int done = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[1] : 0;
     // level 3 (the default): one pass until a chain has asked, then two passes while chains keep asking; levels 1 and 2:
     // two passes always
-    R.two_pass = b->use_cache != 3 || !b->h_wait_hint || (asked > 0 && asked > done - 2);
+    R.two_pass = b->use_cache < 3 || !b->h_wait_hint || (asked > 0 && asked > done - 2);
     if (b->n_runs == 0x3fffffff && b->h_wait_hint) b->h_wait_hint[0] = b->h_wait_hint[1] = 0; // (the run numbers wrap)
   }
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
@@ -1016,7 +1017,7 @@ int lt_batch_cache_stats(lt_batch *b, int64_t stats[7])
 
 int lt_batch_set_window_cache(lt_batch *b, int on)
 {
-  if (!b || on < 0 || on > 3) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0, 1, 2 or 3");
+  if (!b || on < 0 || on > 4) return fail(LT_ERROR_INVALID_INPUTS, "window cache must be 0 ... 4");
   HIP_TRY(hipSetDevice(b->device));
   if ((on == 0) != (b->d_cache == nullptr)) { // the cache's memory goes with level 0 and comes back with 1 / 2
     if (b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));

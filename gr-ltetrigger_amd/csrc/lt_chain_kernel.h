@@ -58,6 +58,7 @@ struct ChainArgs {
   int *wait_hint;      // two words of pinned host memory (or null): [0] set to run_id by a chain that has enough searches ahead
   int run_id;          // of it to ask for the cache -- whether the run has one or not --, [1] by the kernel as such (pass 0):
                        // the host's cue to give the next runs two passes or one
+  int stream;          // window cache level 4: an untracked chain asks for its lag-metric STREAM instead of windows (below)
 };
 constexpr int kCacheStripLags = 64 * kStripRegs;   // 896 floats per (slot, strip)
 constexpr int kCacheMinSearches = 6;               // fewer searches ahead than this: not worth a pass of its own
@@ -91,51 +92,10 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
   }
 }
 
-// srslte_pss_find_pss on the window whose strip samples are in x (strip_load).  resolve = false: lag metric and
-// exponential average only (a window the scan has already turned into a record).  Contains workgroup
-// barriers; `buf` alternates between calls.
-// cached: the window's lag metric as lt_metric_kernel left it (12 x 896 floats) -- the transforms are skipped, the
-// average and everything after it run as ever (x is not looked at then).
-// Round 3 pulled the NEXT slot's lines into the L2 during a cached search, with fourteen loads into one register that
-// nobody reads, left in flight past their block of assembly -- a register the compiler is free to reuse under them
-// (ADVICE r3; an instrumented build of this kernel faulted).  The loads are gone; measured on one box against the
-// version with them, per-chain kernel of a 64-channel step at -4 / 0 dB: 1.92 / 1.21 ms without, 1.91 / 1.21 with --
-// they bought nothing.  What is left of the mechanism is the plain wait at the top of the search after a cached one.
-// (Safe prefetches that were measured and do not pay: the same loads closed by a wait of their own, +15 %: the search
-// then waits for the next slot's HBM latency; one or two LDS-DMA loads, a sector per lane, into a dump area, +8 %; LDS-DMA
-// of the whole strip into the wave's idle exchange area, +3 %: an LDS-DMA instruction costs the wave ~300 cycles to issue.)
-struct WarmUp {
-  float sink = 0.f;
-  bool on = false;
-};
-__device__ __forceinline__ void warm_up_landed(WarmUp &wu)
+// The second half of a search: the average is up to date in the strips' registers; peak, lobe and side-lobe maximum
+// (srslte_pss_find_pss after the average, oracle/lte_oracle.c:295-316).
+__device__ __forceinline__ SearchResult chain_search_resolve(ChainLds &L, int w, int lane, ema_t &ema, int &buf, bool resolve)
 {
-  if (wu.on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wu.sink)::"memory");
-  wu.on = false;
-}
-__device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane, ema_t &ema, int &buf,
-                                                     bool resolve, WarmUp &wu, const float *cached = nullptr,
-                                                     const float *cache_end = nullptr)
-{
-  fft::c32 *e = L.E + w * fft::kScratchW;
-  warm_up_landed(wu);
-  if (cached) {
-    float met[kStripRegs];
-    const float *m = cached + (size_t)w * kCacheStripLags + lane;
-#pragma unroll
-    for (int r = 0; r < kStripRegs; ++r) met[r] = m[64 * r];
-    // The slot after this one is what the chain will want next if it stays on its grid: its lines are pulled into
-    // this XCD's L2 now, so that the search after this one finds them there instead of in HBM (WarmUp above).
-    if (cached + cache_slot_floats() < cache_end) {
-      const float *n = m + cache_slot_floats();
-      wu.on = true;
-      (void)n; // (round 3 issued fourteen loads into wu.sink here and left them in flight: removed, see below)
-    }
-    strip_ema_apply(w, lane, met, ema);
-  } else {
-    strip_fft<false>(lane, x, L.TW1, L.TW2, e);
-    strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
-  }
   SearchResult out;
   out.peak_pos = 0;
   out.peak_value = 0.f;
@@ -206,10 +166,206 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[
   return out;
 }
 
-__device__ __forceinline__ void chain_run(const ChainArgs &a)
+// ---------------------------------------------------------------- lag-metric stream (window cache level 4)
+// A window's lag metric at lag l, 127 <= l < 9600, is |sum_k h[k] x[w0 + l - k]|^2 with every sample inside the window:
+// it depends on the absolute position w0 + l alone, not on where the window starts.  So for a chain whose grid may move
+// with every hit (an untracked chain: idle, or building its score at marginal SNR) the window cache holds not windows
+// but the chain's STREAM, S[i] = |sum_k h[k] x[o + i - k]|^2 for every sample position from o on -- overlap-save blocks
+// of 896 outputs, 12 to a slot, formed by lt_metric_kernel like the windows' strips -- and whatever grid the chain is
+// on, a search reads its interior lags out of it (one unaligned, coalesced load per register) and forms the 253 edge
+// lags, whose sums stop at the window's first or last sample (lags 0..126 and 9600..9725), directly: 12 waves x 64 lanes,
+// a third of the taps each.
+// The stream's blocks are not the window's strips: the same sums in another order of rounding.  Level 4 is therefore
+// NOT bit-identical to levels 0..3 (which are, among themselves); it matches them, and the oracle, to the tolerance the
+// parity tests give the device's own transform against the oracle's (tests/test_gpu_stream.py).
+constexpr int kStreamBlock = kCacheStripLags;           // 896 stream elements per block = per (slot, strip)
+constexpr int kStreamSlot = kStrips * kStreamBlock;     // 10752 per slot
+constexpr int kStreamBack = 1024;                       // the stream starts this far in front of the chain's position:
+                                                        // one hit moves the grid back by at most 960
+constexpr int kEdgeHead = kSymbolSz - 1;                // lags 0..126: the sum stops at the window's first sample
+constexpr int kEdgeTail = kNLags - kHalfFrame;          // lags 9600..9725: ... at its last
+constexpr int kEdgeShare = kChainWaves / 2;             // lanes (in as many waves) that share the 128 products of a pair of edge lags
+constexpr int kEdgeTaps = (kSymbolSz + kEdgeShare - 1) / kEdgeShare; // 22 taps each
+struct StreamLds {
+  v2f xs[2 * kSymbolSz];          // window samples 0..126 at [0, 127), 9473..9599 at [128, 255)
+  v2f taps[kEdgeShare * kEdgeTaps]; // (zeros from 128 on)
+  v2f part[2][kChainWaves / 2][kSymbolSz]; // [head, tail][share of the taps][unit]
+};
+
+// the 1024 samples of the overlap-save block that starts at absolute sample a0 (zero outside the capture)
+__device__ __forceinline__ void stream_block_load(const Capture &c, int64_t a0, int lane, fft::c32 (&x)[16])
+{
+  const int64_t lo = a0 - c.t0;
+  if (lo >= 0 && lo + fft::kN <= c.n) {
+    const v2f *p = c.iq + lo + lane;
+#pragma unroll
+    for (int R = 0; R < 16; ++R) x[R] = p[64 * R];
+  } else {
+#pragma unroll
+    for (int R = 0; R < 16; ++R) x[R] = ld_abs(c, a0 + lane + 64 * R);
+  }
+}
+
+// met[r] = lag metric of lag c0 + lane + 64 r of the window at w0; s0 = the stream element of the window's lag 0 (all of
+// [s0, s0 + 9726) exists).  Two workgroup barriers.
+__device__ __forceinline__ void stream_metric(StreamLds &S, const Capture &cap, int64_t w0, const float *__restrict__ s0, int w,
+                                              int lane, float (&met)[kStripRegs])
+{
+  const int c0 = kStripPitch * w - kStripHalo;
+#pragma unroll
+  for (int r = 0; r < kStripRegs; ++r) {
+    int idx = c0 + lane + 64 * r;
+    idx = idx < 0 ? 0 : idx > kNLags - 1 ? kNLags - 1 : idx; // (lags outside [0, 9726) are dropped by strip_ema_apply)
+    met[r] = s0[idx];
+  }
+  const int tid = 64 * w + lane;
+  if (tid < 2 * kEdgeHead) {
+    const bool head = tid < kEdgeHead;
+    const int j = head ? tid : tid - kEdgeHead;
+    const int i = head ? j : kHalfFrame - kEdgeHead + j; // the window's sample
+    const int64_t lo = w0 - cap.t0;
+    S.xs[head ? j : kSymbolSz + j] = (lo >= 0 && lo + kHalfFrame <= cap.n) ? cap.iq[lo + i] : ld_abs(cap, w0 + i);
+  }
+  __syncthreads();
+  {
+    // The partial sums of the workgroup's 253 edge lags, wave w's share (between the two barriers of stream_metric).
+    // Head lag l (taps 0..l) and tail lag 9600 + l (taps l + 1..127) make one unit of exactly 128 products, l = 0..126;
+    // six lanes -- in six waves -- share a unit, 22 consecutive taps each (the last 18): every lane of the workgroup
+    // has the same work.  Wave w: units 64 (w / 6) + lane, taps from 22 (w % 6) on.
+    const int half = w / kEdgeShare, j = w - kEdgeShare * half;
+    const int l = 64 * half + lane, k0 = kEdgeTaps * j;
+    float hr = 0.f, hi = 0.f, tr = 0.f, ti = 0.f;
+    // (in three batches, every LDS read of a batch in flight before its first product: left to itself the compiler
+    // reads, waits and multiplies tap by tap.  Tap k is a head tap for the lanes with l >= k and a tail tap for the others:
+    // each product goes into both sums, with zero for the sample in the one it does not belong to.  Sixteen vector
+    // instructions a tap, four cycles each, three waves to a SIMD: ~1.7 us of a search's ~7.  Measured and no faster:
+    // the sums switched instead of masked, and the five waves whose taps are all of one kind spared the masks.  A version
+    // without masks -- zeros in LDS around the samples -- halves the instructions and does not fit the kernel's registers.)
+    constexpr int kB = (kEdgeTaps + 2) / 3;
+  #pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      v2f h[kB], x[kB];
+  #pragma unroll
+      for (int i = 0; i < kB; ++i) {
+        const int k = k0 + kB * b + i; // (up to 131: the taps from 128 on are zeros)
+        if (kB * b + i >= kEdgeTaps) continue;
+        // sample l - k of the window for the head lag (k <= l), 9600 + l - k = 9473 + (127 + l - k) for the tail's
+        h[i] = S.taps[k];
+        x[i] = S.xs[k <= l ? l - k : 2 * kSymbolSz - 1 + l - k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int i = 0; i < kB; ++i) {
+        if (kB * b + i >= kEdgeTaps) continue;
+        const bool head = k0 + kB * b + i <= l;
+        const float xhr = head ? x[i].x : 0.f, xhi = head ? x[i].y : 0.f, xtr = head ? 0.f : x[i].x, xti = head ? 0.f : x[i].y;
+        hr = fmaf(h[i].x, xhr, hr);
+        hr = fmaf(-h[i].y, xhi, hr);
+        hi = fmaf(h[i].x, xhi, hi);
+        hi = fmaf(h[i].y, xhr, hi);
+        tr = fmaf(h[i].x, xtr, tr);
+        tr = fmaf(-h[i].y, xti, tr);
+        ti = fmaf(h[i].x, xti, ti);
+        ti = fmaf(h[i].y, xtr, ti);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    S.part[0][j][l] = v2f{hr, hi};
+    S.part[1][j][l] = v2f{tr, ti};
+  }
+  __syncthreads();
+  if (w == 0 || w == kStrips - 1) {
+    const int first = w == 0 ? 0 : kHalfFrame, n = w == 0 ? kEdgeHead : kEdgeTail;
+    const v2f(*part)[kSymbolSz] = S.part[w == 0 ? 0 : 1];
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) {
+      if (!((w == 0 && r < 3) || (w != 0 && r >= kStripRegs - 3))) continue;
+      const int e = c0 + lane + 64 * r - first; // index among the edge lags = the unit
+      if (e >= 0 && e < n) {
+        const v2f p0 = part[0][e], p1 = part[1][e], p2 = part[2][e], p3 = part[3][e], p4 = part[4][e], p5 = part[5][e];
+        const float yr = ((p0.x + p1.x) + (p2.x + p3.x)) + (p4.x + p5.x), yi = ((p0.y + p1.y) + (p2.y + p3.y)) + (p4.y + p5.y);
+        met[r] = yr * yr + yi * yi;
+      }
+    }
+  }
+}
+
+// srslte_pss_find_pss on the window whose strip samples are in x (strip_load).  resolve = false: lag metric and
+// exponential average only (a window the scan has already turned into a record).  Contains workgroup
+// barriers; `buf` alternates between calls.
+// cached: the window's lag metric as lt_metric_kernel left it (12 x 896 floats) -- the transforms are skipped, the
+// average and everything after it run as ever (x is not looked at then).
+// Round 3 pulled the NEXT slot's lines into the L2 during a cached search, with fourteen loads into one register that
+// nobody reads, left in flight past their block of assembly -- a register the compiler is free to reuse under them
+// (ADVICE r3; an instrumented build of this kernel faulted).  The loads are gone; measured on one box against the
+// version with them, per-chain kernel of a 64-channel step at -4 / 0 dB: 1.92 / 1.21 ms without, 1.91 / 1.21 with --
+// they bought nothing.  What is left of the mechanism is the plain wait at the top of the search after a cached one.
+// (Safe prefetches that were measured and do not pay: the same loads closed by a wait of their own, +15 %: the search
+// then waits for the next slot's HBM latency; one or two LDS-DMA loads, a sector per lane, into a dump area, +8 %; LDS-DMA
+// of the whole strip into the wave's idle exchange area, +3 %: an LDS-DMA instruction costs the wave ~300 cycles to issue.)
+struct WarmUp {
+  float sink = 0.f;
+  bool on = false;
+};
+__device__ __forceinline__ void warm_up_landed(WarmUp &wu)
+{
+  if (wu.on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wu.sink)::"memory");
+  wu.on = false;
+}
+struct StreamSearch { // a search out of the chain's stream (level 4)
+  StreamLds *lds = nullptr;
+  Capture cap = {}; // (by value: a pointer would pin the chain's copy to memory)
+  int64_t w0 = 0;
+  const float *s0 = nullptr; // the stream element of the window's lag 0; null: not a stream search
+};
+template <bool kStream = false>
+__device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane, ema_t &ema, int &buf,
+                                                     bool resolve, WarmUp &wu, const float *cached = nullptr,
+                                                     const float *cache_end = nullptr, const StreamSearch &ss = StreamSearch())
+{
+  fft::c32 *e = L.E + w * fft::kScratchW;
+  warm_up_landed(wu);
+  if (cached) {
+    float met[kStripRegs];
+    const float *m = cached + (size_t)w * kCacheStripLags + lane;
+#pragma unroll
+    for (int r = 0; r < kStripRegs; ++r) met[r] = m[64 * r];
+    // The slot after this one is what the chain will want next if it stays on its grid: its lines are pulled into
+    // this XCD's L2 now, so that the search after this one finds them there instead of in HBM (WarmUp above).
+    if (cached + cache_slot_floats() < cache_end) {
+      const float *n = m + cache_slot_floats();
+      wu.on = true;
+      (void)n; // (round 3 issued fourteen loads into wu.sink here and left them in flight: removed, see below)
+    }
+    strip_ema_apply(w, lane, met, ema);
+  } else if (kStream && ss.s0) {
+    float met[kStripRegs];
+    int ws = w; // (opaque like the lane: what depends on the wave's number is formed here, not held across the chain's loop)
+    asm volatile("" : "+s"(ws));
+    stream_metric(*ss.lds, ss.cap, ss.w0, ss.s0, ws, lane, met);
+    strip_ema_apply(w, lane, met, ema);
+  } else {
+    strip_fft<false>(lane, x, L.TW1, L.TW2, e);
+    strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
+  }
+  return chain_search_resolve(L, w, lane, ema, buf, resolve);
+}
+
+template <bool kStream> __device__ __forceinline__ StreamLds *stream_lds()
+{
+  if constexpr (kStream) {
+    __shared__ StreamLds s;
+    return &s;
+  } else {
+    return nullptr;
+  }
+}
+
+template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArgs &a)
 {
   __shared__ ChainLds L;
   __shared__ float psr_data[kMovingAvgSz];
+  StreamLds *const SL = stream_lds<kStream>();
   constexpr int NT = kChainThreads;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -246,6 +402,36 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
     int64_t ahead = first <= last_start ? (last_start - first) / ((int64_t)stride * kHalfFrame) + 1 : 0;
     if (ahead > kCacheMaxPerChain) ahead = kCacheMaxPerChain;
     if (ahead >= kCacheMinSearches && a.wait_hint && tid == 0) *reinterpret_cast<volatile int *>(a.wait_hint) = a.run_id;
+    if constexpr (kStream) {
+      // level 4, an untracked chain: its stream from a little in front of where it stands to the last lag of the last
+      // window it can search -- as far as kCacheMaxPerChain slots reach (beyond them: the transforms)
+      if (a.cache && a.stream && ahead >= kCacheMinSearches && !st->is_tracking) {
+        __shared__ int s_sbase;
+        const int64_t o = first - kStreamBack;
+        int64_t want = (last_start + kNLags - o + kStreamSlot - 1) / kStreamSlot;
+        if (want > kCacheMaxPerChain) want = kCacheMaxPerChain;
+        if (tid == 0) s_sbase = atomicAdd(a.slot_next, (int)want);
+        __syncthreads();
+        const int base = s_sbase;
+        const int got = a.slot_cap - base < (int)want ? a.slot_cap - base : (int)want;
+        if (got >= 2) {
+          for (int i = tid; i < got; i += NT) {
+            a.slot_owner[base + i] = make_int2(chain, -1 - i); // (second member negative: a slot of a stream)
+            a.slot_pos[base + i] = o + (int64_t)i * kStreamSlot;
+          }
+          if (tid == 0) {
+            atomicAdd(a.launch_slots, got);
+            atomicAdd(a.slot_next + 3, 1); // diagnostics
+            st->cache_pos = o;
+            st->cache_base = base;
+            st->cache_n = got;
+            st->cache_stride = 0; // (0: a stream)
+          }
+          return;
+        }
+        ahead = 0; // (no room: nothing to ask for)
+      }
+    }
     if (a.cache && ahead >= kCacheMinSearches) {
       __shared__ int s_base;
       if (tid == 0) s_base = atomicAdd(a.slot_next, (int)ahead);
@@ -272,7 +458,8 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
   const float *cache0 = nullptr;
   int64_t cache_pos = 0, cache_step = 1;
   int cache_n = 0;
-  if (a.cache && a.pass == 1 && st->cache_n > 0) {
+  // (a chain with a stream, level 4: the same variables, cache_step = 0 -- cache_pos is where the stream starts, cache_n its slots)
+  if (a.cache && a.pass == 1 && st->cache_n > 0 && (kStream || st->cache_stride > 0)) {
     cache0 = a.cache + (size_t)st->cache_base * cache_slot_floats();
     cache_pos = st->cache_pos;
     cache_step = (int64_t)st->cache_stride * kHalfFrame;
@@ -300,6 +487,13 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
   const int redo_stride = st->pre_stride;
   for (int i = tid; i < kMovingAvgSz; i += NT) psr_data[i] = st->psr_data[i];
   chain_lds_init(L, a.tab, n_id_2);
+  if constexpr (kStream) {
+    if (tid < kEdgeShare * kEdgeTaps) {
+      const cf32 h = a.tab->pss_taps[n_id_2][tid < kSymbolSz ? tid : 0];
+      SL->taps[tid] = tid < kSymbolSz ? v2f{h.re, h.im} : v2f{0.f, 0.f};
+    }
+    if (tid < 2) SL->xs[kSymbolSz * tid + kEdgeHead] = v2f{0.f, 0.f}; // (the two elements no search writes)
+  }
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
   uint32_t psr_i = st->psr_i;
@@ -371,7 +565,7 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
       fft::c32 x[16];
       // the window's lag metric may be in the cache (pass 1, a window on the grid the chain stood on in pass 0)
       const float *cached = nullptr;
-      if (cache_n > 0 && wpos >= cache_pos) {
+      if (cache_n > 0 && wpos >= cache_pos && (!kStream || cache_step != 0)) {
         int64_t kq;
         if (wpos == cache_next_pos) { // (the usual case: no division)
           kq = cache_next_k;
@@ -386,9 +580,23 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
           cache_next_pos = wpos + cache_step;
         }
       }
-      if (!cached) strip_load(cap, wpos, w, ln, x);
-      if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached ? 5 : 6) : (cached ? 1 : 2)), 1); // diagnostics
-      const SearchResult r = chain_search(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end);
+      bool streamed = false;
+      if constexpr (kStream) {
+        const int64_t d = wpos - cache_pos;
+        streamed = cache_n > 0 && cache_step == 0 && d >= 0 && d + kNLags <= (int64_t)cache_n * kStreamSlot;
+      }
+      if (!cached && !streamed) strip_load(cap, wpos, w, ln, x);
+      if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached || streamed ? 5 : 6) : (cached || streamed ? 1 : 2)), 1); // diagnostics
+      StreamSearch ss;
+      if constexpr (kStream) {
+        if (streamed) {
+          ss.lds = SL;
+          ss.cap = cap;
+          ss.w0 = wpos;
+          ss.s0 = cache0 + (wpos - cache_pos);
+        }
+      }
+      const SearchResult r = chain_search<kStream>(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end, ss);
       searched = true;
       if (redo) {
         redo_k++;
@@ -490,9 +698,9 @@ __device__ __forceinline__ void chain_run(const ChainArgs &a)
 // them (lib/pss_impl.cc:199-204): the CFO estimate of each (eight records per wave at a time) and, in call order, the
 // ring with mean_cfo() (one wave), 768 records per turn; and the chain's tracked half-frames go onto the work list of
 // the per-record kernels (one atomic per 64 records), which rotate them by that mean (lt_kernels.hip).
-__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
+template <bool kStream> __device__ __forceinline__ void chain_kernel_body(const ChainArgs &a)
 {
-  chain_run(a);
+  chain_run<kStream>(a);
   // (the host's cue, lt_api.cpp: this run's per-chain kernel has run -- so every launch of the run before is through)
   if (a.pass == 0 && a.wait_hint && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(a.wait_hint)[1] = a.run_id;
   __threadfence_block();
@@ -563,10 +771,12 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     __syncthreads();
     if (any_lost && lane == 0) t_lost = 1; // (benign race: every writer writes 1)
     // ---- srslte_pss_cfo_compute on the uncorrected PSS symbol of every tracked half-frame (lib/pss_impl.cc:199-201)
-    for (int g = w * 8 + (lane >> 3); g < n_ran; g += kChainWaves * 8) {
+    int lc = lane; // (opaque per turn, like the ring's below: nothing lane-dependent of the estimate is kept across the turns)
+    asm volatile("" : "+v"(lc));
+    for (int g = w * 8 + (lc >> 3); g < n_ran; g += kChainWaves * 8) {
       const int local = t_idx[g];
-      const float c = cfo_estimate_group8(taps, cap, t_pos[g] + (kSlotLen - kSymbolSz), lane);
-      if ((lane & 7) == 0) {
+      const float c = cfo_estimate_group8(taps, cap, t_pos[g] + (kSlotLen - kSymbolSz), lc);
+      if ((lc & 7) == 0) {
         t_cfo[local] = c;
         recs[b0 + local].cfo = c;
       }
@@ -595,6 +805,9 @@ __global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a)
     cfo_ring_end(st, t_ring, ring, ln);
   }
 }
+__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a) { chain_kernel_body<false>(a); }
+// ... with the lag-metric stream of window cache level 4
+__global__ __launch_bounds__(kChainThreads) void lt_chain_stream_kernel(ChainArgs a) { chain_kernel_body<true>(a); }
 
 // ---------------------------------------------------------------- window cache: the lag metric in bulk
 // The lag metric of a window does not depend on the chain's state, only the average that follows it does: for the
@@ -637,7 +850,9 @@ __global__ __launch_bounds__(64 * kMetricWaves) void lt_metric_kernel(MetricArgs
   fft::c32 *e = E + w * fft::kScratchW;
   for (int item = blockIdx.x * kMetricWaves + w; item < n_items; item += gridDim.x * kMetricWaves) {
     const int slot = slot0 + item / kStrips, strip = item % kStrips;
-    const int chain = __builtin_amdgcn_readfirstlane(a.slot_owner[slot].x);
+    const int2 owner = a.slot_owner[slot];
+    const int chain = __builtin_amdgcn_readfirstlane(owner.x);
+    const bool of_stream = __builtin_amdgcn_readfirstlane(owner.y) < 0; // (level 4: twelve blocks of a chain's stream)
     const int64_t wpos = uniform_i64(a.slot_pos[slot]);
     Capture cap;
     cap.iq = a.iq + (int64_t)(chain / 3) * a.ch_stride;
@@ -648,7 +863,9 @@ __global__ __launch_bounds__(64 * kMetricWaves) void lt_metric_kernel(MetricArgs
     int ln = lane;
     asm volatile("" : "+v"(ln));
     fft::c32 x[16];
-    strip_load(cap, wpos, strip, ln, x);
+    // (a stream's block: outputs 128..1023 are the stream elements wpos + 896 strip + 0..895)
+    if (of_stream) stream_block_load(cap, wpos + (int64_t)strip * kStreamBlock - (fft::kN - kStreamBlock), ln, x);
+    else strip_load(cap, wpos, strip, ln, x);
     strip_fft<false>(ln, x, TW1, TW2, e);
     v2f spec[16];
 #pragma unroll

@@ -58,6 +58,7 @@ struct RunLaunch {
   int *wait_hint = nullptr;   // device view of two words in pinned host memory: the number of the last run in which a chain had
                               // enough searches ahead of it to ask for the window cache, and of the last run the per-chain kernel ran in
   int run_id = 0;             // this run's number (from 1)
+  int stream = 0;             // window cache level 4: untracked chains ask for their lag-metric stream (lt_chain_kernel.h)
   int two_pass = 1;           // 0: the per-chain kernel in one pass without the cache (no lt_metric_kernel, no second launch):
                               // no chain asked in the latest run the caller knows in full.  Timing only, never a record
   int list_slot = 0;          // which of the two work lists (and of their counters behind the job counters) this run uses (0 / 1)

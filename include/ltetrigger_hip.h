@@ -176,7 +176,7 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
-/* Window cache (default 3).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
+/* Window cache, levels 0 to 4 (default 3).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
  * cell, every chain in mode 0 -- the per-chain kernel takes in two passes: the first lists the windows every such chain
  * has ahead of it on its present timing, lt_metric_kernel forms their lag metrics for all chains at once, chip-wide,
  * and the second pass runs general_work on them (a window off the list goes through the transforms there and then).
@@ -187,7 +187,18 @@ int lt_batch_get_mode(lt_batch *b);
  * in which run a chain last had enough searches ahead of it to ask; a run enqueued when the latest run the host knows in
  * full had none -- and every run before the first such report -- launches the kernel once, without the cache (two launches
  * fewer per run; a capture that turns marginal pays its first runs' searches through the transforms until the report is in).
- * 0 = every search through the transforms.  Same records at every level.
+ * 0 = every search through the transforms.  Levels 0 to 3 give the same records bit for bit.
+ * Level 4 = level 3 with lag-metric STREAMS for the chains that are not tracking: at marginal SNR most hits move a chain's
+ * timing, and every window after such a hit is off the list (at -4 dB two searches in three went through the transforms
+ * at level 3).  An interior lag of a window (127 <= lag < 9600) depends on the absolute sample position only, so for such
+ * a chain lt_metric_kernel forms |sum_k h[k] x[p - k]|^2 for EVERY position p from the chain's position to the end of the
+ * chunk (the same overlap-save blocks, laid on the stream instead of on windows), and a search on whatever timing reads
+ * its interior lags out of the stream and forms the 253 edge lags (whose sums stop at the window's first or last sample)
+ * directly.  Tracking chains keep their windows.  The stream's blocks round differently from a window's strips: level 4
+ * matches the oracle under the same bar as every level (integer, index and flag fields equal, everything downstream of
+ * the lag metric bit-exact, PSR / peak value within 1e-4) but NOT the bits of levels 0 to 3 -- and since it is the
+ * host's cue that decides whether a run has the second pass at all, its low bits may differ from run to run.  Made for
+ * sweeps at marginal SNR (bench.py's config5 leg); not the default.
  * Footprint: min(3 n_channels x windows of max_samples, 16384) slots of 43 008 bytes -- 705 MB at most --, allocated by
  * lt_batch_create, freed by level 0 and allocated again by 1 / 2 (if the memory cannot be had the batch runs as at level 0).
  * The slots of a scan round (levels 2 / 3, up to four channels) are free again after the round: a capture of any length

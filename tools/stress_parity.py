@@ -72,6 +72,11 @@ def main():
     ap.add_argument("--variants", type=int, default=0,
                     help="per scene, this many more runs with a random execution mode, window-cache level, workgroup shape and "
                          "round lengths: their records bit for bit those of the default run")
+    ap.add_argument("--window-cache", type=int, default=-1,
+                    help="lt_batch_set_window_cache level of the runs held against the oracle (default: the library's)")
+    ap.add_argument("--runs", type=int, default=1,
+                    help="run every scene this many times on one batch (lt_batch_reset between) and compare the last run's records: levels "
+                         "3 and 4 give a fresh batch's first run one pass, the cache -- or the stream -- comes with the second")
     ap.add_argument("--scan-groups", type=int, default=0,
                     help="strips per scan workgroup (lt_batch_set_scan_groups): 0 = as the batch size chooses (one for scenes this small), "
                          "3 = the benchmark's shape (hand-over between waves that share SIMDs, issue priorities)")
@@ -118,6 +123,7 @@ def main():
     n_samples = 0
     n_scenes = 0
     n_variants = 0
+    n_cached = n_transformed = 0  # searches of the per-chain kernel's second pass: out of the window cache, through the transforms
     for seed, iq, kw in scenes():
         want = O.batch_run(iq, nthreads=min(os.cpu_count() or 1, 16), **kw)
         n_scenes += 1
@@ -126,6 +132,8 @@ def main():
             b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
             b.set_mode(mode)
             b.set_scan_groups(args.scan_groups)
+            if args.window_cache >= 0:
+                b.set_window_cache(args.window_cache)
             if args.chunks:
                 r = np.random.default_rng(seed * 7 + mode)
                 n = iq.shape[1]
@@ -140,8 +148,14 @@ def main():
                         parts[c].append(recs.copy())
                 got = [np.concatenate(p) for p in parts]
             else:
-                b.run_host(iq)
-                got = b.collect()
+                for k in range(args.runs):
+                    if k:
+                        b.reset()
+                    b.run_host(iq)
+                    got = b.collect()
+                used = b.cache_stats()
+                n_cached += used[1] + used[5]
+                n_transformed += used[2] + used[6]
             b.close()
             for c in range(len(want)):
                 n_records += len(want[c])
@@ -221,6 +235,7 @@ def main():
         if args.variants and not args.chunks:
             b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
             b.set_scan_groups(args.scan_groups)
+            b.set_window_cache(3)  # (levels 0 to 3 give the same bits; level 4 is held against the oracle, not against them)
             b.run_host(iq)
             ref = [r.copy() for r in b.collect()]
             b.close()
@@ -248,7 +263,8 @@ def main():
                         break
         if n_scenes % 20 == 0:
             print(f"{n_scenes} scenes, {len(bad)} differ, {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
-    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups, "chunks": bool(args.chunks), "stack": args.stack, "variant_runs": n_variants,
+    res = {"scenes": n_scenes, "samples": n_samples, "records_compared": n_records, "modes": [1, 0], "scan_groups": args.scan_groups, "window_cache": args.window_cache, "runs": args.runs,
+           "second_pass_searches": {"cached_or_streamed": n_cached, "transformed": n_transformed}, "chunks": bool(args.chunks), "stack": args.stack, "variant_runs": n_variants,
            "differing": bad, "arg_max_between_lags_equal_to_1e-4": ties, "seconds": round(time.time() - t_start, 1)}
     print(json.dumps(res))
     if args.out:
