@@ -13,6 +13,7 @@
 // takes the exact path: the average goes to an LDS mirror and the walk of oracle/lte_oracle.c:300-316 runs on it.
 #pragma once
 #include <cstddef>
+#include <type_traits>
 
 #include "lt_records.h"
 #include "lt_scan_kernels.h"
@@ -94,7 +95,8 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
 
 // The second half of a search: the average is up to date in the strips' registers; peak, lobe and side-lobe maximum
 // (srslte_pss_find_pss after the average, oracle/lte_oracle.c:295-316).
-__device__ __forceinline__ SearchResult chain_search_resolve(ChainLds &L, int w, int lane, ema_t &ema, int &buf, bool resolve)
+template <class Lds>
+__device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int lane, ema_t &ema, int &buf, bool resolve)
 {
   SearchResult out;
   out.peak_pos = 0;
@@ -174,7 +176,14 @@ __device__ __forceinline__ SearchResult chain_search_resolve(ChainLds &L, int w,
 // of 896 outputs, 12 to a slot, formed by lt_metric_kernel like the windows' strips -- and whatever grid the chain is
 // on, a search reads its interior lags out of it (one unaligned, coalesced load per register) and forms the 253 edge
 // lags, whose sums stop at the window's first or last sample (lags 0..126 and 9600..9725), directly: 12 waves x 64 lanes,
-// a third of the taps each.
+// 22 taps of a pair of edge lags each.  The chains with a stream run in a kernel of their own between the two passes of
+// lt_chain_kernel (lt_chain_stream_kernel = chain_run<true>: the same general_work, no transforms -- 106 registers and
+// 56 KB of LDS instead of 168 and 140); a window the stream does not hold ends their part, and pass 1 takes them up.
+// Where a search's time goes there (cycle stamps of wave 0, -4 dB, 162 searches of one chain, 17.5 k cycles = 7.3 us each):
+// edge lags 34 %, peak / lobe / side-lobe maximum 31 %, state machine and record 18 %, average 9 %, the stream's loads 9 %.
+// Measured in that kernel and no faster (each 3..5 % slower): the edge sums without masks (zeros in LDS around the samples:
+// half the vector instructions), and the next window's loads taken a search early on the guess that the chain stays on its
+// timing, parked in LDS -- twelve waves of one workgroup on one CU are bound by what each has to issue, and both add to it.
 // The stream's blocks are not the window's strips: the same sums in another order of rounding.  Level 4 is therefore
 // NOT bit-identical to levels 0..3 (which are, among themselves); it matches them, and the oracle, to the tolerance the
 // parity tests give the device's own transform against the oracle's (tests/test_gpu_stream.py).
@@ -312,16 +321,9 @@ __device__ __forceinline__ void warm_up_landed(WarmUp &wu)
   if (wu.on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wu.sink)::"memory");
   wu.on = false;
 }
-struct StreamSearch { // a search out of the chain's stream (level 4)
-  StreamLds *lds = nullptr;
-  Capture cap = {}; // (by value: a pointer would pin the chain's copy to memory)
-  int64_t w0 = 0;
-  const float *s0 = nullptr; // the stream element of the window's lag 0; null: not a stream search
-};
-template <bool kStream = false>
 __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane, ema_t &ema, int &buf,
                                                      bool resolve, WarmUp &wu, const float *cached = nullptr,
-                                                     const float *cache_end = nullptr, const StreamSearch &ss = StreamSearch())
+                                                     const float *cache_end = nullptr)
 {
   fft::c32 *e = L.E + w * fft::kScratchW;
   warm_up_landed(wu);
@@ -338,12 +340,6 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[
       (void)n; // (round 3 issued fourteen loads into wu.sink here and left them in flight: removed, see below)
     }
     strip_ema_apply(w, lane, met, ema);
-  } else if (kStream && ss.s0) {
-    float met[kStripRegs];
-    int ws = w; // (opaque like the lane: what depends on the wave's number is formed here, not held across the chain's loop)
-    asm volatile("" : "+s"(ws));
-    stream_metric(*ss.lds, ss.cap, ss.w0, ss.s0, ws, lane, met);
-    strip_ema_apply(w, lane, met, ema);
   } else {
     strip_fft<false>(lane, x, L.TW1, L.TW2, e);
     strip_root_update(w, lane, x, L.SPEC, L.TW1, L.TW2, e, ema);
@@ -351,21 +347,21 @@ __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[
   return chain_search_resolve(L, w, lane, ema, buf, resolve);
 }
 
-template <bool kStream> __device__ __forceinline__ StreamLds *stream_lds()
+// LDS of the stream kernel (lt_chain_stream_kernel): no transforms, so no exchange areas, twiddles or spectrum -- the
+// mirror of the exact path, the strips' partial results and what the edge lags need
+struct LeanLds {
+  alignas(16) v2f E[(kConvLen + 8 + 1) / 2]; // (named as in ChainLds: chain_search_resolve's mirror of the average)
+  StripPartial parts[2][kStrips];
+  float wave_out[kChainWaves];
+  StreamLds stream;
+};
+// kLean: the stream kernel's version (window cache level 4, between pass 0 and pass 1 of the kernel proper) -- the chains
+// with a stream only, every search out of the stream, no transforms (and none of their registers and LDS); at a window the
+// stream does not hold it puts the chain down as it stands, for pass 1 to take up
+template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs &a)
 {
-  if constexpr (kStream) {
-    __shared__ StreamLds s;
-    return &s;
-  } else {
-    return nullptr;
-  }
-}
-
-template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArgs &a)
-{
-  __shared__ ChainLds L;
+  __shared__ std::conditional_t<kLean, LeanLds, ChainLds> L;
   __shared__ float psr_data[kMovingAvgSz];
-  StreamLds *const SL = stream_lds<kStream>();
   constexpr int NT = kChainThreads;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -373,6 +369,9 @@ template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArg
   const int chain = blockIdx.x, channel = chain / 3, n_id_2 = chain % 3;
   ChainState *st = a.state + chain;
   if (st->run_done) return; // the resolver has seen the chain stop for this run
+  if constexpr (kLean) {
+    if (!(a.cache && st->cache_n > 0 && st->cache_stride == 0)) return;
+  }
 
   Capture cap;
   cap.iq = a.iq + (int64_t)channel * a.ch_stride;
@@ -395,19 +394,21 @@ template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArg
   // everything to pass 1.  An idle or acquiring chain searches every window from pos on; a tracked one every
   // (track_every + 1)-th from its next search on.  (Windows its average still has to be run through -- pre_n -- are
   // found in the cache if they lie on the same grid, and go through the transforms if not.)
-  if ((a.cache || a.wait_hint) && a.pass == 0 && can_call(pos) && nrec < a.rec_cap) {
+  if (!kLean && (a.cache || a.wait_hint) && a.pass == 0 && can_call(pos) && nrec < a.rec_cap) {
     const int stride = st->is_tracking ? a.track_every + 1 : 1;
     const int64_t first = pos + (st->is_tracking ? (int64_t)st->timer * kHalfFrame : 0);
     const int64_t last_start = a.flush ? t1 - kHalfFrame : t1 - kCallReach; // last position a call may start at
     int64_t ahead = first <= last_start ? (last_start - first) / ((int64_t)stride * kHalfFrame) + 1 : 0;
     if (ahead > kCacheMaxPerChain) ahead = kCacheMaxPerChain;
     if (ahead >= kCacheMinSearches && a.wait_hint && tid == 0) *reinterpret_cast<volatile int *>(a.wait_hint) = a.run_id;
-    if constexpr (kStream) {
+    {
       // level 4, an untracked chain: its stream from a little in front of where it stands to the last lag of the last
       // window it can search -- as far as kCacheMaxPerChain slots reach (beyond them: the transforms)
       if (a.cache && a.stream && ahead >= kCacheMinSearches && !st->is_tracking) {
         __shared__ int s_sbase;
-        const int64_t o = first - kStreamBack;
+        // (from the first of the windows its average still has to go through, if there are any: they come first)
+        int64_t o = first - kStreamBack;
+        if (st->pre_n > 0 && st->pre_pos < o) o = st->pre_pos;
         int64_t want = (last_start + kNLags - o + kStreamSlot - 1) / kStreamSlot;
         if (want > kCacheMaxPerChain) want = kCacheMaxPerChain;
         if (tid == 0) s_sbase = atomicAdd(a.slot_next, (int)want);
@@ -459,7 +460,7 @@ template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArg
   int64_t cache_pos = 0, cache_step = 1;
   int cache_n = 0;
   // (a chain with a stream, level 4: the same variables, cache_step = 0 -- cache_pos is where the stream starts, cache_n its slots)
-  if (a.cache && a.pass == 1 && st->cache_n > 0 && (kStream || st->cache_stride > 0)) {
+  if (a.cache && a.pass == 1 && st->cache_n > 0 && (kLean || st->cache_stride > 0)) {
     cache0 = a.cache + (size_t)st->cache_base * cache_slot_floats();
     cache_pos = st->cache_pos;
     cache_step = (int64_t)st->cache_stride * kHalfFrame;
@@ -486,13 +487,14 @@ template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArg
   const int64_t redo_pos0 = st->pre_pos;
   const int redo_stride = st->pre_stride;
   for (int i = tid; i < kMovingAvgSz; i += NT) psr_data[i] = st->psr_data[i];
-  chain_lds_init(L, a.tab, n_id_2);
-  if constexpr (kStream) {
+  if constexpr (kLean) {
     if (tid < kEdgeShare * kEdgeTaps) {
       const cf32 h = a.tab->pss_taps[n_id_2][tid < kSymbolSz ? tid : 0];
-      SL->taps[tid] = tid < kSymbolSz ? v2f{h.re, h.im} : v2f{0.f, 0.f};
+      L.stream.taps[tid] = tid < kSymbolSz ? v2f{h.re, h.im} : v2f{0.f, 0.f};
     }
-    if (tid < 2) SL->xs[kSymbolSz * tid + kEdgeHead] = v2f{0.f, 0.f}; // (the two elements no search writes)
+    if (tid < 2) L.stream.xs[kSymbolSz * tid + kEdgeHead] = v2f{0.f, 0.f}; // (the two elements no search writes)
+  } else {
+    chain_lds_init(L, a.tab, n_id_2);
   }
   int is_tracking = st->is_tracking, score = st->score, timer = st->timer;
   int tracking_lost = st->tracking_lost, peak_pos = st->peak_pos;
@@ -562,41 +564,38 @@ template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArg
       // and mask of the search out of the loop and spills them across it)
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      fft::c32 x[16];
-      // the window's lag metric may be in the cache (pass 1, a window on the grid the chain stood on in pass 0)
-      const float *cached = nullptr;
-      if (cache_n > 0 && wpos >= cache_pos && (!kStream || cache_step != 0)) {
-        int64_t kq;
-        if (wpos == cache_next_pos) { // (the usual case: no division)
-          kq = cache_next_k;
-        } else {
-          const int64_t d = wpos - cache_pos;
-          kq = d / cache_step;
-          if (kq * cache_step != d) kq = -1;
-        }
-        if (kq >= 0 && kq < cache_n) {
-          cached = cache0 + (size_t)kq * cache_slot_floats();
-          cache_next_k = (int)kq + 1;
-          cache_next_pos = wpos + cache_step;
-        }
-      }
-      bool streamed = false;
-      if constexpr (kStream) {
+      SearchResult r;
+      if constexpr (kLean) {
         const int64_t d = wpos - cache_pos;
-        streamed = cache_n > 0 && cache_step == 0 && d >= 0 && d + kNLags <= (int64_t)cache_n * kStreamSlot;
-      }
-      if (!cached && !streamed) strip_load(cap, wpos, w, ln, x);
-      if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached || streamed ? 5 : 6) : (cached || streamed ? 1 : 2)), 1); // diagnostics
-      StreamSearch ss;
-      if constexpr (kStream) {
-        if (streamed) {
-          ss.lds = SL;
-          ss.cap = cap;
-          ss.w0 = wpos;
-          ss.s0 = cache0 + (wpos - cache_pos);
+        if (!(d >= 0 && d + kNLags <= (int64_t)cache_n * kStreamSlot)) break; // not in the stream: pass 1's, through the transforms
+        if (tid == 0) atomicAdd(a.slot_next + (redo ? 5 : 1), 1); // diagnostics
+        float met[kStripRegs];
+        stream_metric(L.stream, cap, wpos, cache0 + d, w, ln, met);
+        strip_ema_apply(w, ln, met, ema);
+        r = chain_search_resolve(L, w, ln, ema, buf, !redo);
+      } else {
+        fft::c32 x[16];
+        // the window's lag metric may be in the cache (pass 1, a window on the grid the chain stood on in pass 0)
+        const float *cached = nullptr;
+        if (cache_n > 0 && wpos >= cache_pos) {
+          int64_t kq;
+          if (wpos == cache_next_pos) { // (the usual case: no division)
+            kq = cache_next_k;
+          } else {
+            const int64_t d = wpos - cache_pos;
+            kq = d / cache_step;
+            if (kq * cache_step != d) kq = -1;
+          }
+          if (kq >= 0 && kq < cache_n) {
+            cached = cache0 + (size_t)kq * cache_slot_floats();
+            cache_next_k = (int)kq + 1;
+            cache_next_pos = wpos + cache_step;
+          }
         }
+        if (!cached) strip_load(cap, wpos, w, ln, x);
+        if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached ? 5 : 6) : (cached ? 1 : 2)), 1); // diagnostics
+        r = chain_search(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end);
       }
-      const SearchResult r = chain_search<kStream>(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end, ss);
       searched = true;
       if (redo) {
         redo_k++;
@@ -698,9 +697,9 @@ template <bool kStream> __device__ __forceinline__ void chain_run(const ChainArg
 // them (lib/pss_impl.cc:199-204): the CFO estimate of each (eight records per wave at a time) and, in call order, the
 // ring with mean_cfo() (one wave), 768 records per turn; and the chain's tracked half-frames go onto the work list of
 // the per-record kernels (one atomic per 64 records), which rotate them by that mean (lt_kernels.hip).
-template <bool kStream> __device__ __forceinline__ void chain_kernel_body(const ChainArgs &a)
+__device__ __forceinline__ void chain_kernel_body(const ChainArgs &a)
 {
-  chain_run<kStream>(a);
+  chain_run<false>(a);
   // (the host's cue, lt_api.cpp: this run's per-chain kernel has run -- so every launch of the run before is through)
   if (a.pass == 0 && a.wait_hint && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(a.wait_hint)[1] = a.run_id;
   __threadfence_block();
@@ -805,9 +804,10 @@ template <bool kStream> __device__ __forceinline__ void chain_kernel_body(const 
     cfo_ring_end(st, t_ring, ring, ln);
   }
 }
-__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a) { chain_kernel_body<false>(a); }
-// ... with the lag-metric stream of window cache level 4
-__global__ __launch_bounds__(kChainThreads) void lt_chain_stream_kernel(ChainArgs a) { chain_kernel_body<true>(a); }
+__global__ __launch_bounds__(kChainThreads) void lt_chain_kernel(ChainArgs a) { chain_kernel_body(a); }
+// Window cache level 4, between the two passes of the kernel above: the chains that asked for their lag-metric stream run
+// general_work on it as far as it reaches (chain_run<true>); everything else -- their tails too -- is pass 1's.
+__global__ __launch_bounds__(kChainThreads) void lt_chain_stream_kernel(ChainArgs a) { chain_run<true>(a); }
 
 // ---------------------------------------------------------------- window cache: the lag metric in bulk
 // The lag metric of a window does not depend on the chain's state, only the average that follows it does: for the

@@ -767,8 +767,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.run_id = R.run_id;
     if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && R.cache_level >= 1 && R.two_pass)) c.cache = nullptr;
     c.stream = R.stream && c.cache;
-    auto chain_kernel = c.stream ? lt_chain_stream_kernel : lt_chain_kernel;
-    hipLaunchKernelGGL(chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+    hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     if (c.cache) {
       // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
       MetricArgs m;
@@ -779,7 +778,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
       hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);
       c.pass = 1;
-      hipLaunchKernelGGL(chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+      // (level 4: the chains with a stream first, in the kernel that has nothing but the stream to search in)
+      if (c.stream) hipLaunchKernelGGL(lt_chain_stream_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+      hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     }
   }
   if (R.ev_chain_done) (void)hipEventRecord(R.ev_chain_done, stream);
