@@ -27,10 +27,10 @@ bash tools/pmc_scan.sh gr-ltetrigger_amd/build/scan_bench lt_scan_kernel 64 64 7
 bash tools/pmc_scan.sh python3 lt_decim tools/decim_probe.py 16 50 > "$OUT/${TAG}_pmc_decim_kernel.txt" 2>&1
 for a in "4 16" "8 64" "16 50" "16 1" "8 1"; do python tools/decim_probe.py $a; done > "$OUT/${TAG}_decim_probe.txt" 2>&1
 # marginal cells: a step's kernels at -4 and 0 dB
-for snr in -4 0; do
-  rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_snr$snr" -- python3 bench.py --snr-db $snr --steps 6 --warmup 2 --no-end-to-end --no-config2 --no-config5 --no-cpu-baseline --no-overlap-leg --no-steady-leg > "$OUT/bench_snr$snr.json" 2> /dev/null
-  { echo "== bench.py --snr-db $snr (64 channels x 1 s): the kernels of one step"; python tools/timeline.py "$OUT/prof_snr$snr"; } >> "$OUT/${TAG}_timeline_marginal.txt"
-done
+for level in 3 4; do for snr in -4 0; do
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_snr${snr}_l$level" -- python3 bench.py --snr-db $snr --window-cache $level --steps 6 --warmup 3 --no-end-to-end --no-config2 --no-config5 --no-cpu-baseline --no-overlap-leg --no-steady-leg > "$OUT/bench_snr${snr}_l$level.json" 2> /dev/null
+  { echo "== bench.py --snr-db $snr --window-cache $level (64 channels x 1 s): the kernels of one step"; python tools/timeline.py "$OUT/prof_snr${snr}_l$level"; } >> "$OUT/${TAG}_timeline_marginal.txt"
+done; done
 for a in "64 64 7 1" "64 64 3 1" "64 64 1 1" "64 64 7 2" "64 64 7 3"; do
   echo "== scan_bench $a"
   { gr-ltetrigger_amd/build/scan_bench $a 2>&1 | grep "^scan\|checksum" | tail -2; } 2>/dev/null
@@ -38,4 +38,6 @@ done > "$OUT/${TAG}_scan_bench.txt" 2>&1
 gr-ltetrigger_amd/build/scan_bench_prof 64 64 7 1 > "$OUT/${TAG}_scan_phases.txt" 2>&1
 timeout -k 10 500 python tools/stress_parity.py --scenes 300 --seed0 9000 --out "$OUT/stress" > "$OUT/stress.json" 2> "$OUT/stress.err"
 cp "$OUT/stress/stress_parity.json" "$OUT/${TAG}_stress_parity.json"
+timeout -k 10 500 python tools/stress_parity.py --scenes 300 --seed0 9000 --window-cache 4 --runs 2 --out "$OUT/stress_l4" > "$OUT/stress_l4.json" 2> "$OUT/stress_l4.err"
+cp "$OUT/stress_l4/stress_parity.json" "$OUT/${TAG}_stress_parity_level4.json"
 echo ALLDONE
