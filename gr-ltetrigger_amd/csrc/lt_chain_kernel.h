@@ -95,6 +95,10 @@ __device__ __forceinline__ void chain_lds_init(ChainLds &L, const DeviceTables *
 
 // The second half of a search: the average is up to date in the strips' registers; peak, lobe and side-lobe maximum
 // (srslte_pss_find_pss after the average, oracle/lte_oracle.c:295-316).
+#ifdef LT_PROF
+__device__ unsigned int lt_prof_walks; // searches that took the walk over the whole average (all chains, all launches)
+__device__ unsigned long long lt_prof_q[4]; // wave 0's cycles in strip_resolve / at the barrier / in resolve_window, and the searches
+#endif
 template <class Lds>
 __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int lane, ema_t &ema, int &buf, bool resolve)
 {
@@ -104,16 +108,38 @@ __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int 
   out.psr = 0.f;
   if (!resolve) return out;
   StripPartial p;
+#ifdef LT_PROF
+  const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
   strip_resolve(ema, w, lane, p);
+#ifdef LT_PROF
+  const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+#endif
   StripPartial *parts = L.parts[buf];
   buf ^= 1;
   if (lane == 0) parts[w] = p;
   __syncthreads();
-  const WindowResult r = resolve_window_unrolled(parts); // (the reads of a loop in flight together, not in turn)
+#ifdef LT_PROF
+  const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+#endif
+  WindowResult r;
+  if constexpr (std::is_same<Lds, ChainLds>::value) r = resolve_window_unrolled(parts); // (the reads of a loop in flight together, not in turn)
+  else r = resolve_window_lanes(parts, lane);
+#ifdef LT_PROF
+  if (threadIdx.x == 0) {
+    atomicAdd(&lt_prof_q[0], q1 - q0);
+    atomicAdd(&lt_prof_q[1], q2 - q1);
+    atomicAdd(&lt_prof_q[2], (unsigned long long)__builtin_amdgcn_s_memtime() - q2 + (r.peak_pos & 0)); // (after the window's results exist)
+    atomicAdd(&lt_prof_q[3], 1ull);
+  }
+#endif
   out.peak_pos = __builtin_amdgcn_readfirstlane(r.peak_pos);
   out.peak_value = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.peak_value)));
   out.psr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r.psr)));
   if (__builtin_amdgcn_readfirstlane((int)r.exact)) return out;
+#ifdef LT_PROF
+  if (threadIdx.x == 0) atomicAdd(&lt_prof_walks, 1u);
+#endif
   // ---- exact path (oracle/lte_oracle.c:295-316 on the whole vector): the peak is right as it is; the lobe
   // walk and the side-lobe maximum run on a mirror of the average in LDS (the exchange areas are idle now)
   float *M = reinterpret_cast<float *>(L.E);
@@ -181,9 +207,14 @@ __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int 
 // 56 KB of LDS instead of 168 and 140); a window the stream does not hold ends their part, and pass 1 takes them up.
 // Where a search's time goes there (cycle stamps of wave 0, -4 dB, 162 searches of one chain, 17.5 k cycles = 7.3 us each):
 // edge lags 34 %, peak / lobe / side-lobe maximum 31 %, state machine and record 18 %, average 9 %, the stream's loads 9 %.
-// Measured in that kernel and no faster (each 3..5 % slower): the edge sums without masks (zeros in LDS around the samples:
-// half the vector instructions), and the next window's loads taken a search early on the guess that the chain stays on its
-// timing, parked in LDS -- twelve waves of one workgroup on one CU are bound by what each has to issue, and both add to it.
+// (Those shares are of the kernel's first version: edge sums of sixteen masked vector instructions a tap, taps and samples
+// from LDS, and the twelve partials combined by every wave in two scalar loops.)  Twelve waves of one workgroup on one CU are
+// bound by what they issue and by what they move through LDS, so what paid was less of both: the edge sums without masks
+// (zeros in LDS around the samples), the taps in scalar registers and two packed FMAs a tap (-7 % at -4 dB; without the
+// scalar taps the unmasked sums read twice the LDS bytes and were 4 % slower), the twelve partials combined by twelve lanes
+// (resolve_window_lanes: -6 %).  What did not, three times over: loads taken a search early on the guess that the chain stays
+// on its timing (right 63 % of the time at -4 dB) -- the stream's values parked in LDS (+4 %), the same as plain loads into
+// registers nobody reads, to warm this XCD's L2 (+5 %), the edge samples alone, straight into their place in LDS (+3 %).
 // The stream's blocks are not the window's strips: the same sums in another order of rounding.  Level 4 is therefore
 // NOT bit-identical to levels 0..3 (which are, among themselves); it matches them, and the oracle, to the tolerance the
 // parity tests give the device's own transform against the oracle's (tests/test_gpu_stream.py).
@@ -195,11 +226,43 @@ constexpr int kEdgeHead = kSymbolSz - 1;                // lags 0..126: the sum 
 constexpr int kEdgeTail = kNLags - kHalfFrame;          // lags 9600..9725: ... at its last
 constexpr int kEdgeShare = kChainWaves / 2;             // lanes (in as many waves) that share the 128 products of a pair of edge lags
 constexpr int kEdgeTaps = (kSymbolSz + kEdgeShare - 1) / kEdgeShare; // 22 taps each
+constexpr int kPadH = 72, kPadT0 = 8, kPadT = 88;
+constexpr int kXh = kPadH, kXt = kPadH + kSymbolSz + kPadT0, kXsLen = kXt + kSymbolSz + kPadT;
 struct StreamLds {
-  v2f xs[2 * kSymbolSz];          // window samples 0..126 at [0, 127), 9473..9599 at [128, 255)
-  v2f taps[kEdgeShare * kEdgeTaps]; // (zeros from 128 on)
+  // the window's first and last 127 samples, with zeros where a lane's taps reach past them: a head sum's taps beyond its
+  // lag (k > l) read the zeros in front of the head samples, a tail sum's taps up to its lag (k <= l) those behind the
+  // tail's -- the sums need no masks.  (The pads are as wide as the lanes of one wave are apart from their taps.)
+  v2f xs[kXsLen]; // xs[kXh + i] = window sample i, xs[kXt + i] = window sample 9473 + i, i < 127; zeros elsewhere
   v2f part[2][kChainWaves / 2][kSymbolSz]; // [head, tail][share of the taps][unit]
 };
+typedef const __attribute__((address_space(4))) unsigned long long *const_taps_t; // (re, im) pairs in constant memory
+
+// acc += sum over kEdgeTaps taps of tap * sample, the taps wave-uniform (scalar registers), the samples at p[kEdgeTaps - 1 - i]
+// in LDS: per tap two packed FMAs -- (re, im) += h.re * (x.re, x.im); (re, im) += (-h.im, h.im) * (x.im, x.re) -- which is the
+// per-component order of the oracle's complex product (re: h.re x.re - h.im x.im; im: h.re x.im + h.im x.re).
+__device__ __forceinline__ v2f edge_sum(const_taps_t taps, const v2f *p)
+{
+  v2f acc = {0.f, 0.f};
+  constexpr int kNB = 2, kB = (kEdgeTaps + kNB - 1) / kNB;
+#pragma unroll
+  for (int b = 0; b < kNB; ++b) {
+    unsigned long long h[kB];
+    v2f x[kB];
+#pragma unroll
+    for (int i = 0; i < kB; ++i) {
+      if (kB * b + i >= kEdgeTaps) continue;
+      h[i] = taps[kB * b + i];
+      x[i] = p[kEdgeTaps - 1 - (kB * b + i)];
+    }
+#pragma unroll
+    for (int i = 0; i < kB; ++i) {
+      if (kB * b + i >= kEdgeTaps) continue;
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(h[i]), "v"(x[i]));
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "s"(h[i]), "v"(x[i]));
+    }
+  }
+  return acc;
+}
 
 // the 1024 samples of the overlap-save block that starts at absolute sample a0 (zero outside the capture)
 __device__ __forceinline__ void stream_block_load(const Capture &c, int64_t a0, int lane, fft::c32 (&x)[16])
@@ -217,8 +280,8 @@ __device__ __forceinline__ void stream_block_load(const Capture &c, int64_t a0, 
 
 // met[r] = lag metric of lag c0 + lane + 64 r of the window at w0; s0 = the stream element of the window's lag 0 (all of
 // [s0, s0 + 9726) exists).  Two workgroup barriers.
-__device__ __forceinline__ void stream_metric(StreamLds &S, const Capture &cap, int64_t w0, const float *__restrict__ s0, int w,
-                                              int lane, float (&met)[kStripRegs])
+__device__ __forceinline__ void stream_metric(StreamLds &S, const Capture &cap, int64_t w0, const float *__restrict__ s0,
+                                              const_taps_t taps, int w, int lane, float (&met)[kStripRegs])
 {
   const int c0 = kStripPitch * w - kStripHalo;
 #pragma unroll
@@ -233,7 +296,7 @@ __device__ __forceinline__ void stream_metric(StreamLds &S, const Capture &cap, 
     const int j = head ? tid : tid - kEdgeHead;
     const int i = head ? j : kHalfFrame - kEdgeHead + j; // the window's sample
     const int64_t lo = w0 - cap.t0;
-    S.xs[head ? j : kSymbolSz + j] = (lo >= 0 && lo + kHalfFrame <= cap.n) ? cap.iq[lo + i] : ld_abs(cap, w0 + i);
+    S.xs[(head ? kXh : kXt) + j] = (lo >= 0 && lo + kHalfFrame <= cap.n) ? cap.iq[lo + i] : ld_abs(cap, w0 + i);
   }
   __syncthreads();
   {
@@ -243,42 +306,15 @@ __device__ __forceinline__ void stream_metric(StreamLds &S, const Capture &cap, 
     // has the same work.  Wave w: units 64 (w / 6) + lane, taps from 22 (w % 6) on.
     const int half = w / kEdgeShare, j = w - kEdgeShare * half;
     const int l = 64 * half + lane, k0 = kEdgeTaps * j;
-    float hr = 0.f, hi = 0.f, tr = 0.f, ti = 0.f;
-    // (in three batches, every LDS read of a batch in flight before its first product: left to itself the compiler
-    // reads, waits and multiplies tap by tap.  Tap k is a head tap for the lanes with l >= k and a tail tap for the others:
-    // each product goes into both sums, with zero for the sample in the one it does not belong to.  Sixteen vector
-    // instructions a tap, four cycles each, three waves to a SIMD: ~1.7 us of a search's ~7.  Measured and no faster:
-    // the sums switched instead of masked, and the five waves whose taps are all of one kind spared the masks.  A version
-    // without masks -- zeros in LDS around the samples -- halves the instructions and does not fit the kernel's registers.)
-    constexpr int kB = (kEdgeTaps + 2) / 3;
-  #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      v2f h[kB], x[kB];
-  #pragma unroll
-      for (int i = 0; i < kB; ++i) {
-        const int k = k0 + kB * b + i; // (up to 131: the taps from 128 on are zeros)
-        if (kB * b + i >= kEdgeTaps) continue;
-        // sample l - k of the window for the head lag (k <= l), 9600 + l - k = 9473 + (127 + l - k) for the tail's
-        h[i] = S.taps[k];
-        x[i] = S.xs[k <= l ? l - k : 2 * kSymbolSz - 1 + l - k];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-      for (int i = 0; i < kB; ++i) {
-        if (kB * b + i >= kEdgeTaps) continue;
-        const bool head = k0 + kB * b + i <= l;
-        const float xhr = head ? x[i].x : 0.f, xhi = head ? x[i].y : 0.f, xtr = head ? 0.f : x[i].x, xti = head ? 0.f : x[i].y;
-        hr = fmaf(h[i].x, xhr, hr);
-        hr = fmaf(-h[i].y, xhi, hr);
-        hi = fmaf(h[i].x, xhi, hi);
-        hi = fmaf(h[i].y, xhr, hi);
-        tr = fmaf(h[i].x, xtr, tr);
-        tr = fmaf(-h[i].y, xti, tr);
-        ti = fmaf(h[i].x, xti, ti);
-        ti = fmaf(h[i].y, xtr, ti);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    // Tap k belongs to the head sum of the lanes with l >= k and to the tail sum of the others.  Seven of the twelve waves
+    // have lanes of both kinds and form both sums over all their taps -- the taps of the wrong kind meet zeros --; in the
+    // other five every tap is a tail tap (units 0..63, taps from 66 on) or a head tap (units 64..127, taps up to 43).
+    const int l_lo = 64 * half, k_hi = k0 + kEdgeTaps - 1 < kSymbolSz - 1 ? k0 + kEdgeTaps - 1 : kSymbolSz - 1;
+    const int d = l - k0 - (kEdgeTaps - 1);
+    v2f hs = {0.f, 0.f}, ts = {0.f, 0.f};
+    if (k0 <= l_lo + 63) hs = edge_sum(taps + k0, S.xs + kXh + d);            // sample l - k
+    if (k_hi > l_lo) ts = edge_sum(taps + k0, S.xs + kXt + kEdgeHead + d);    // sample 9473 + (127 + l - k)
+    const float hr = hs.x, hi = hs.y, tr = ts.x, ti = ts.y;
     S.part[0][j][l] = v2f{hr, hi};
     S.part[1][j][l] = v2f{tr, ti};
   }
@@ -355,6 +391,13 @@ struct LeanLds {
   float wave_out[kChainWaves];
   StreamLds stream;
 };
+// Diagnostics build (-DLT_PROF): shader-clock stamps of wave 0 around the phases of a search out of the stream, summed over
+// the chain's searches and printed per chain (device printf) -- where DESIGN 4.3's shares come from.
+#ifdef LT_PROF
+#define LT_STAMP(i) (prof_t[i] = __builtin_amdgcn_s_memtime())
+#else
+#define LT_STAMP(i) ((void)0)
+#endif
 // kLean: the stream kernel's version (window cache level 4, between pass 0 and pass 1 of the kernel proper) -- the chains
 // with a stream only, every search out of the stream, no transforms (and none of their registers and LDS); at a window the
 // stream does not hold it puts the chain down as it stands, for pass 1 to take up
@@ -488,11 +531,7 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
   const int redo_stride = st->pre_stride;
   for (int i = tid; i < kMovingAvgSz; i += NT) psr_data[i] = st->psr_data[i];
   if constexpr (kLean) {
-    if (tid < kEdgeShare * kEdgeTaps) {
-      const cf32 h = a.tab->pss_taps[n_id_2][tid < kSymbolSz ? tid : 0];
-      L.stream.taps[tid] = tid < kSymbolSz ? v2f{h.re, h.im} : v2f{0.f, 0.f};
-    }
-    if (tid < 2) L.stream.xs[kSymbolSz * tid + kEdgeHead] = v2f{0.f, 0.f}; // (the two elements no search writes)
+    if (tid < kXsLen) L.stream.xs[tid] = v2f{0.f, 0.f}; // (the pads: no search writes them)
   } else {
     chain_lds_init(L, a.tab, n_id_2);
   }
@@ -528,7 +567,19 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
     dst[5] = u4{0xffffffffu, 0xffffffffu, __float_as_uint(pmax), (uint32_t)tm}; // n_id_1 = cell_id = -1
   };
 
+#ifdef LT_PROF
+  unsigned long long prof_t[5] = {0, 0, 0, 0, 0}, prof_sum[5] = {0, 0, 0, 0, 0}, prof_first = 0;
+#endif
   for (;;) {
+#ifdef LT_PROF
+    if (kLean && prof_t[3]) { // the search before: its phases, and what followed it up to here
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      prof_sum[0] += prof_t[1] - prof_t[0]; prof_sum[1] += prof_t[2] - prof_t[1]; prof_sum[2] += prof_t[3] - prof_t[2];
+      prof_sum[3] += now - prof_t[3]; prof_sum[4] += 1;
+      if (!prof_first) prof_first = prof_t[0];
+      prof_t[4] = now; prof_t[3] = 0;
+    }
+#endif
     const bool callable = can_call(pos) && nrec < a.rec_cap;
     // the windows the average still has to go through come first: before the first search, or -- if no call fits
     // into this chunk any more -- before the kernel ends
@@ -563,16 +614,20 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
       // (the lane index is made opaque per iteration: otherwise the compiler hoists every lane-dependent address
       // and mask of the search out of the loop and spills them across it)
       int ln = lane;
-      asm volatile("" : "+v"(ln));
+      if constexpr (!kLean) asm volatile("" : "+v"(ln)); // (the stream kernel has the registers: its lane-dependent offsets stay)
       SearchResult r;
       if constexpr (kLean) {
         const int64_t d = wpos - cache_pos;
         if (!(d >= 0 && d + kNLags <= (int64_t)cache_n * kStreamSlot)) break; // not in the stream: pass 1's, through the transforms
         if (tid == 0) atomicAdd(a.slot_next + (redo ? 5 : 1), 1); // diagnostics
         float met[kStripRegs];
-        stream_metric(L.stream, cap, wpos, cache0 + d, w, ln, met);
+        LT_STAMP(0);
+        stream_metric(L.stream, cap, wpos, cache0 + d, (const_taps_t)(uintptr_t)a.tab->pss_taps_pad[n_id_2], w, ln, met);
+        LT_STAMP(1);
         strip_ema_apply(w, ln, met, ema);
+        LT_STAMP(2);
         r = chain_search_resolve(L, w, ln, ema, buf, !redo);
+        LT_STAMP(3);
       } else {
         fft::c32 x[16];
         // the window's lag metric may be in the cache (pass 1, a window on the grid the chain stood on in pass 0)
@@ -671,6 +726,11 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
     pos = next_pos;
   }
 
+#ifdef LT_PROF
+  if (kLean && tid == 0 && prof_sum[4] > 100)
+    printf("PROF chain %d searches %llu: stream+edges %llu average %llu resolve %llu rest %llu of %llu cycles; walks so far (all chains) %u; all chains so far: strip_resolve %llu barrier %llu resolve_window %llu of %llu searches\n", chain, prof_sum[4],
+           prof_sum[0], prof_sum[1], prof_sum[2], prof_sum[3], prof_t[4] - prof_first, lt_prof_walks, lt_prof_q[0], lt_prof_q[1], lt_prof_q[2], lt_prof_q[3]);
+#endif
   warm_up_landed(warm);
   // ---- store state
   __syncthreads();

@@ -316,6 +316,41 @@ template <typename Ptr> __device__ __forceinline__ WindowResult resolve_window_u
   return w;
 }
 
+// The same by twelve lanes of a wave, one partial each (the stream kernel, every wave for itself): one LDS round trip, the
+// two maxima by the wave reductions the strips use, the peak strip's fields by lane reads -- instead of thirty-odd
+// dependent LDS reads and two scalar loops per wave.  Same decisions, same values: the first maximum in strip order is the
+// lowest lane that holds the wave's maximum; the side-lobe maximum is a maximum, in whatever order.
+__device__ __forceinline__ WindowResult resolve_window_lanes(const StripPartial *parts, int lane)
+{
+  const bool on = lane < kStrips;
+  const StripPartial q = parts[on ? lane : 0];
+  const float m1 = on ? q.m1 : -FLT_MAX;
+  const float bm = wave_max_dpp(m1);
+  const uint64_t hit = __ballot(on && m1 == bm);
+  const int best = hit ? __builtin_ctzll(hit) : 0; // (no lane equal: only a NaN can do that -- stay in bounds)
+  WindowResult w;
+  const uint32_t bflags = (uint32_t)__builtin_amdgcn_readlane((int)q.flags, best);
+  const int p1b = __builtin_amdgcn_readlane(q.p1, best);
+  const int lb = __builtin_amdgcn_readlane(q.lb, best), ub = __builtin_amdgcn_readlane(q.ub, best);
+  const float sb = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(q.s), best));
+  const float bmv = hit ? bm : __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(q.m1), 0));
+  w.exact = !(bflags & kPartWide);
+  w.peak_value = bmv;
+  w.peak_pos = (bmv > -FLT_MAX) ? p1b : 0;
+  const bool other = on && lane != best;
+  const bool inside = q.p1 >= lb && q.p1 < ub; // that strip's maximum lies on the slope of this lobe
+  if (__ballot(other && inside && (q.flags & kPartWide))) w.exact = false;
+  const float v = other ? (inside ? q.s : q.m1) : -FLT_MAX;
+  const float ov = wave_max_dpp(v);
+  const float out = ov > sb ? ov : sb;
+  const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(q.a0), 0));
+  const float sl = (w.peak_pos <= 2) ? a0 : out;
+  const float sr = (ub >= kNLags) ? 0.f : out;
+  const float side = sl > sr ? sl : sr;
+  w.psr = w.peak_value / side;
+  return w;
+}
+
 // The same for partials in global memory, one lane per window (the resolver kernel): the twelve strips' leading
 // halves (m1, p1, s, lb) are fetched together -- twelve loads in flight instead of twenty-four round trips, one per
 // step of the two loops above -- and what else a window needs (the peak strip's ub and flags; rarely a neighbour's

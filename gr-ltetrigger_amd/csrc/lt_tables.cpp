@@ -87,6 +87,8 @@ void build_device_tables(DeviceTables *t)
 {
   std::memset(t, 0, sizeof *t);
   for (int r = 0; r < 3; ++r) pss_filter(r, t->pss_taps[r]);
+  for (int r = 0; r < 3; ++r)
+    for (int m = 0; m < 128; ++m) t->pss_taps_pad[r][m] = t->pss_taps[r][m]; // (the rest stays zero)
 
   for (int i = 0; i < kCexpTabSize; ++i) {
     const double ph = 2.0 * kPi * (double)i / (double)kCexpTabSize;

@@ -39,6 +39,9 @@ struct DeviceTables {
   cf32 pss_spec[3][1024];
   float fft_tw1[fft::kTw1Len][2];
   float fft_tw2[fft::kTw2Len][2];
+  // the taps once more with zeros behind them: the stream kernel's edge sums read 6 x 22 = 132 of them, wave-uniformly
+  // (scalar loads), csrc/lt_chain_kernel.h
+  cf32 pss_taps_pad[3][136];
 };
 
 void build_device_tables(DeviceTables *t);
