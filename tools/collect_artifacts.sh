@@ -10,7 +10,14 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/final"
 rm -rf "$OUT" && mkdir -p "$OUT"
 set -x
-# the driver's command first (5 + 20 steps on a cold process: the figure the docs lead with), then the defaults (50 + 100)
+# HBM traffic first: bench.py quotes profiles/traffic.json only while its hash matches csrc/ -- the box's copy of the file is
+# replaced by this run's before the bench lines are taken (copy "$OUT/traffic.json" to profiles/ afterwards)
+bash tools/pmc_traffic.sh > "$OUT/pmc_traffic.txt" 2>&1
+cp gpurun_out/pmc/summary.txt "$OUT/${TAG}_pmc_traffic_summary.txt"
+cp gpurun_out/pmc/traffic.json "$OUT/traffic.json"
+cp gpurun_out/pmc/traffic.json profiles/traffic.json
+sleep 20
+# the driver's command (5 + 20 steps on a process that finds the GPU idle: the figure the docs lead with), then the defaults (50 + 100)
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_cmd.json.log" 2> "$OUT/bench_driver.err"
 python bench.py > "$OUT/${TAG}_bench.json.log" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_full" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_under_rocprof.json.log" 2> "$OUT/bench_prof.err"
@@ -20,9 +27,6 @@ rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_overlap" -- python3 b
 python tools/timeline2.py "$OUT/prof_overlap" 3 > "$OUT/${TAG}_timeline_overlap.txt"
 cp "$OUT"/prof_full/*/*kernel_stats.csv "$OUT/${TAG}_kernel_stats.csv"
 cp "$OUT"/prof_path/*/*kernel_stats.csv "$OUT/${TAG}_kernel_stats_path.csv"
-bash tools/pmc_traffic.sh > "$OUT/pmc_traffic.txt" 2>&1
-cp gpurun_out/pmc/summary.txt "$OUT/${TAG}_pmc_traffic_summary.txt"
-cp gpurun_out/pmc/traffic.json "$OUT/traffic.json"
 bash tools/pmc_scan.sh gr-ltetrigger_amd/build/scan_bench lt_scan_kernel 64 64 7 1 > "$OUT/${TAG}_pmc_scan_kernel.txt" 2>&1
 bash tools/pmc_scan.sh python3 lt_decim tools/decim_probe.py 16 50 > "$OUT/${TAG}_pmc_decim_kernel.txt" 2>&1
 for a in "4 16" "8 64" "16 50" "16 1" "8 1"; do python tools/decim_probe.py $a; done > "$OUT/${TAG}_decim_probe.txt" 2>&1
