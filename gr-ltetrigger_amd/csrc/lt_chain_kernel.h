@@ -123,8 +123,7 @@ __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int 
   const unsigned long long q2 = __builtin_amdgcn_s_memtime();
 #endif
   WindowResult r;
-  if constexpr (std::is_same<Lds, ChainLds>::value) r = resolve_window_unrolled(parts); // (the reads of a loop in flight together, not in turn)
-  else r = resolve_window_lanes(parts, lane);
+  r = resolve_window_lanes(parts, lane); // (one LDS round trip and two wave reductions instead of two scalar loops over LDS: lt_scan.h)
 #ifdef LT_PROF
   if (threadIdx.x == 0) {
     atomicAdd(&lt_prof_q[0], q1 - q0);
@@ -203,8 +202,8 @@ __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int 
 // on, a search reads its interior lags out of it (one unaligned, coalesced load per register) and forms the 253 edge
 // lags, whose sums stop at the window's first or last sample (lags 0..126 and 9600..9725), directly: 12 waves x 64 lanes,
 // 22 taps of a pair of edge lags each.  The chains with a stream run in a kernel of their own between the two passes of
-// lt_chain_kernel (lt_chain_stream_kernel = chain_run<true>: the same general_work, no transforms -- 106 registers and
-// 56 KB of LDS instead of 168 and 140); a window the stream does not hold ends their part, and pass 1 takes them up.
+// lt_chain_kernel (lt_chain_stream_kernel = chain_run<true>: the same general_work, no transforms -- 57 KB of LDS
+// instead of 140, nothing spilled); a window the stream does not hold ends their part, and pass 1 takes them up.
 // Where a search's time goes there (cycle stamps of wave 0, -4 dB, 162 searches of one chain, 17.5 k cycles = 7.3 us each):
 // edge lags 34 %, peak / lobe / side-lobe maximum 31 %, state machine and record 18 %, average 9 %, the stream's loads 9 %.
 // (Those shares are of the kernel's first version: edge sums of sixteen masked vector instructions a tap, taps and samples
@@ -212,7 +211,7 @@ __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int 
 // bound by what they issue and by what they move through LDS, so what paid was less of both: the edge sums without masks
 // (zeros in LDS around the samples), the taps in scalar registers and two packed FMAs a tap (-7 % at -4 dB; without the
 // scalar taps the unmasked sums read twice the LDS bytes and were 4 % slower), the twelve partials combined by twelve lanes
-// (resolve_window_lanes: -6 %).  What did not, three times over: loads taken a search early on the guess that the chain stays
+// (resolve_window_lanes: -6 %; in lt_chain_kernel too since: -3 % / -4 % at -4 / 0 dB, level 3).  What did not, three times over: loads taken a search early on the guess that the chain stays
 // on its timing (right 63 % of the time at -4 dB) -- the stream's values parked in LDS (+4 %), the same as plain loads into
 // registers nobody reads, to warm this XCD's L2 (+5 %), the edge samples alone, straight into their place in LDS (+3 %).
 // The stream's blocks are not the window's strips: the same sums in another order of rounding.  Level 4 is therefore

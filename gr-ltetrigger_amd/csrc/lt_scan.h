@@ -271,54 +271,9 @@ template <typename Ptr> __device__ __forceinline__ WindowResult resolve_window(P
   return w;
 }
 
-// The same with both loops unrolled, for partials in LDS (the per-chain kernel, wave-uniform): the maxima are read
-// together, then the fields of the second loop -- 16-byte reads of twelve structures at once would cost 48 registers
-// the per-chain kernel does not have.
-template <typename Ptr> __device__ __forceinline__ WindowResult resolve_window_unrolled(Ptr parts)
-{
-  float m1[kStrips];
-#pragma unroll
-  for (int s = 0; s < kStrips; ++s) m1[s] = parts[s].m1;
-  int best = 0;
-  float bm = m1[0];
-#pragma unroll
-  for (int s = 1; s < kStrips; ++s)
-    if (m1[s] > bm) {
-      bm = m1[s];
-      best = s;
-    }
-  WindowResult w;
-  const uint32_t bflags = parts[best].flags;
-  w.exact = !(bflags & kPartWide);
-  w.peak_value = bm;
-  w.peak_pos = (bm > -FLT_MAX) ? parts[best].p1 : 0;
-  const int lb = parts[best].lb, ub = parts[best].ub;
-  float out = parts[best].s;
-  int p1[kStrips];
-  float sv[kStrips];
-#pragma unroll
-  for (int s = 0; s < kStrips; ++s) {
-    p1[s] = parts[s].p1;
-    sv[s] = parts[s].s;
-  }
-#pragma unroll
-  for (int s = 0; s < kStrips; ++s) {
-    if (s == best) continue;
-    const bool inside = p1[s] >= lb && p1[s] < ub;
-    if (inside && (parts[s].flags & kPartWide)) w.exact = false;
-    const float v = inside ? sv[s] : m1[s];
-    if (v > out) out = v;
-  }
-  const float sl = (w.peak_pos <= 2) ? parts[0].a0 : out;
-  const float sr = (ub >= kNLags) ? 0.f : out;
-  const float side = sl > sr ? sl : sr;
-  w.psr = w.peak_value / side;
-  return w;
-}
-
-// The same by twelve lanes of a wave, one partial each (the stream kernel, every wave for itself): one LDS round trip, the
+// The same by twelve lanes of a wave, one partial each (the per-chain kernels, every wave for itself): one LDS round trip, the
 // two maxima by the wave reductions the strips use, the peak strip's fields by lane reads -- instead of thirty-odd
-// dependent LDS reads and two scalar loops per wave.  Same decisions, same values: the first maximum in strip order is the
+// dependent LDS reads and two scalar loops per wave (rounds 2 to 4's resolve_window_unrolled).  Same decisions, same values: the first maximum in strip order is the
 // lowest lane that holds the wave's maximum; the side-lobe maximum is a maximum, in whatever order.
 __device__ __forceinline__ WindowResult resolve_window_lanes(const StripPartial *parts, int lane)
 {
