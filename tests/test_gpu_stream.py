@@ -107,3 +107,19 @@ def test_stream_with_pushed_chunks(lt, oracle, frames_192):
         assert stats[1] > 0, f"the last chunk's searches must come out of the stream: {stats}"
         for c in range(18):
             assert_records_match(np.concatenate(got[c]), want[c], f"mode {mode} chain {c}")
+
+
+def test_stream_shorter_than_the_capture(lt, oracle, frames_192):
+    """A chain's stream holds 256 slots of 10 752 positions at most (2.75 M samples): in a longer capture the stream kernel
+    puts the chain down where its stream ends and the second pass of the per-chain kernel takes it up, through the
+    transforms -- the records are the oracle's all the same, and both kinds of search have happened."""
+    base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
+    iq, _ = siggen.scan_channels(base, 3, 330 * 9600 + 77, snr_db=-1.0, cfo=True, seed0=911)
+    want = oracle.batch_run(iq, nthreads=8)
+    for mode in (0, 1):
+        got, stats = run_level(lt, iq, 4, mode)
+        assert stats[1] > 200, f"searches out of the streams: {stats}"
+        if mode == 0:
+            assert stats[2] > 20, f"... and, behind their ends, through the transforms: {stats}"
+        for c in range(9):
+            assert_records_match(got[c], want[c], f"mode {mode} chain {c}")
