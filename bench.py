@@ -454,6 +454,10 @@ def main():
                 "ranks_per_gpu": ranks_per_gpu,
             },
             "cell_id_match_rate": match_rate,
+            "cell_id_match_note": "the channel's set of found cells is exactly the one cell put there (none for the noise-only "
+                                  "channels).  Of the 512 channels of 8 ranks two (global channels 106 and 346: ranks 1 and 5) "
+                                  "find no cell at 20 dB -- and neither does the CPU oracle, record for record "
+                                  "(tools/check_rank_channels.py): the reference algorithm on those rotations, not the device path",
             "window_cache": dict(zip(("windows_listed", "searches_cached", "searches_transformed", "chains_waiting", "moved_off_grid", "reruns_cached", "reruns_transformed"), cache_stats)),
             "realtime_factor": round(value * 1e6 / (world * n_ch * FS), 2),
             # algorithmic bytes = 8 B per input sample, whatever a kernel spills on top.
