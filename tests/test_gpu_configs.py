@@ -103,6 +103,16 @@ def test_config5_snr_sweep_detection_equals_oracle(lt, oracle):
                 assert (g["cell_id"], g["nof_prb"], g["nof_tx_ports"]) == (oc["cell_id"], oc["nof_prb"], oc["nof_tx_ports"])
             det.append(bool(g and g["cell_id"] == 369 and g["nof_prb"] == 100))
         rates[snr] = sum(det) / trials
+        if snr == -4:
+            # the knee point once more at window-cache level 4 (lag-metric streams: what bench.py's config5 leg runs at) --
+            # twice, the second pass comes with the second run --: the oracle's records, the same detections
+            bt.batch.set_window_cache(4)
+            for _ in range(2):
+                recs4, events4 = bt.process_device(y)
+            assert bt.batch.cache_stats()[1] > 100, "searches out of the streams"
+            for c in range(3 * trials):
+                assert_records_match(recs4[c], want[c], f"level 4, SNR {snr} dB trial {c // 3} root {c % 3}")
+            assert [ev[0][1] if ev else None for ev in events4] == gpu_cell
     # the knee: detection does not get worse with SNR (between the two points of one length; the knee point has four times
     # the time to find its cell), and the top point detects (mostly)
     assert rates[-6] <= rates[-2] + 0.2 and rates[-6] <= rates[-4] + 0.2, rates
