@@ -339,41 +339,22 @@ __device__ __forceinline__ void stream_metric(StreamLds &S, const Capture &cap, 
 // barriers; `buf` alternates between calls.
 // cached: the window's lag metric as lt_metric_kernel left it (12 x 896 floats) -- the transforms are skipped, the
 // average and everything after it run as ever (x is not looked at then).
-// Round 3 pulled the NEXT slot's lines into the L2 during a cached search, with fourteen loads into one register that
+// (Round 3 pulled the NEXT slot's lines into the L2 during a cached search, with fourteen loads into one register that
 // nobody reads, left in flight past their block of assembly -- a register the compiler is free to reuse under them
-// (an instrumented build of this kernel faulted).  The loads are gone; measured on one box against the
-// version with them, per-chain kernel of a 64-channel step at -4 / 0 dB: 1.92 / 1.21 ms without, 1.91 / 1.21 with --
-// they bought nothing.  What is left of the mechanism is the plain wait at the top of the search after a cached one.
-// (Safe prefetches that were measured and do not pay: the same loads closed by a wait of their own, +15 %: the search
-// then waits for the next slot's HBM latency; one or two LDS-DMA loads, a sector per lane, into a dump area, +8 %; LDS-DMA
-// of the whole strip into the wave's idle exchange area, +3 %: an LDS-DMA instruction costs the wave ~300 cycles to issue.)
-struct WarmUp {
-  float sink = 0.f;
-  bool on = false;
-};
-__device__ __forceinline__ void warm_up_landed(WarmUp &wu)
-{
-  if (wu.on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wu.sink)::"memory");
-  wu.on = false;
-}
+// (an instrumented build of this kernel faulted).  Gone without a trace in round 4: measured on one box against
+// the version with them, per-chain kernel of a 64-channel step at -4 / 0 dB: 1.92 / 1.21 ms without, 1.91 / 1.21 with.  Safe
+// prefetches that were measured and do not pay either: the same loads closed by a wait of their own, +15 %: the search then
+// waits for the next slot's HBM latency; one or two LDS-DMA loads, a sector per lane, into a dump area, +8 %; LDS-DMA of the
+// whole strip into the wave's idle exchange area, +3 %: an LDS-DMA instruction costs the wave ~300 cycles to issue.)
 __device__ __forceinline__ SearchResult chain_search(ChainLds &L, fft::c32 (&x)[16], int w, int lane, ema_t &ema, int &buf,
-                                                     bool resolve, WarmUp &wu, const float *cached = nullptr,
-                                                     const float *cache_end = nullptr)
+                                                     bool resolve, const float *cached = nullptr)
 {
   fft::c32 *e = L.E + w * fft::kScratchW;
-  warm_up_landed(wu);
   if (cached) {
     float met[kStripRegs];
     const float *m = cached + (size_t)w * kCacheStripLags + lane;
 #pragma unroll
     for (int r = 0; r < kStripRegs; ++r) met[r] = m[64 * r];
-    // The slot after this one is what the chain will want next if it stays on its grid: its lines are pulled into
-    // this XCD's L2 now, so that the search after this one finds them there instead of in HBM (WarmUp above).
-    if (cached + cache_slot_floats() < cache_end) {
-      const float *n = m + cache_slot_floats();
-      wu.on = true;
-      (void)n; // (round 3 issued fourteen loads into wu.sink here and left them in flight: removed, see below)
-    }
     strip_ema_apply(w, lane, met, ema);
   } else {
     strip_fft<false>(lane, x, L.TW1, L.TW2, e);
@@ -508,8 +489,6 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
     cache_step = (int64_t)st->cache_stride * kHalfFrame;
     cache_n = st->cache_n;
   }
-  const float *cache_end = cache0 ? cache0 + (size_t)cache_n * cache_slot_floats() : nullptr;
-  WarmUp warm;
   int64_t cache_next_pos = cache_pos; // the window of slot cache_next_k: where a chain that stays on its grid searches next
   int cache_next_k = 0;
 
@@ -648,7 +627,7 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
         }
         if (!cached) strip_load(cap, wpos, w, ln, x);
         if (a.cache && a.pass == 1 && tid == 0) atomicAdd(a.slot_next + (redo ? (cached ? 5 : 6) : (cached ? 1 : 2)), 1); // diagnostics
-        r = chain_search(L, x, w, ln, ema, buf, !redo, warm, cached, cache_end);
+        r = chain_search(L, x, w, ln, ema, buf, !redo, cached);
       }
       searched = true;
       if (redo) {
@@ -730,7 +709,6 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
     printf("PROF chain %d searches %llu: stream+edges %llu average %llu resolve %llu rest %llu of %llu cycles; walks so far (all chains) %u; all chains so far: strip_resolve %llu barrier %llu resolve_window %llu of %llu searches\n", chain, prof_sum[4],
            prof_sum[0], prof_sum[1], prof_sum[2], prof_sum[3], prof_t[4] - prof_first, lt_prof_walks, lt_prof_q[0], lt_prof_q[1], lt_prof_q[2], lt_prof_q[3]);
 #endif
-  warm_up_landed(warm);
   // ---- store state
   __syncthreads();
   if (searched && redo_k >= redo_end) strip_ema_store(avg, w, lane, ema); // (else: the average is described as before)
@@ -964,8 +942,7 @@ __global__ __launch_bounds__(kChainThreads) void lt_find_kernel(const v2f *__res
   int buf = 0;
   fft::c32 x[16];
   strip_load(cap, 0, w, lane, x);
-  WarmUp none;
-  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true, none);
+  const SearchResult r = chain_search(L, x, w, lane, ema, buf, true);
   strip_ema_store(avg, w, lane, ema);
   if (tid == 0) {
     res->peak_pos = r.peak_pos;
