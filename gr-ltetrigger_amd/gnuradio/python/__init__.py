@@ -5,8 +5,11 @@ has NOT been imported anywhere in this repository's environment -- there is no G
 that runs without it is the ``ltetrigger_amd`` package (gr-ltetrigger_amd/__init__.py).
 """
 try:
-    from .ltetrigger_python import *  # noqa: F401,F403  (pybind11 bindings, GNU Radio >= 3.9)
+    from . import ltetrigger_python as blocks_module  # pybind11 bindings, GNU Radio >= 3.9
+    from .ltetrigger_python import *  # noqa: F401,F403
 except ImportError:
-    from ltetrigger_swig import *  # noqa: F401,F403  (GNU Radio 3.7: the reference's SWIG interface file on ../host/ltetrigger/*.h)
+    # GNU Radio 3.7: the reference's SWIG interface file on ../host/ltetrigger/*.h
+    import ltetrigger_swig as blocks_module
+    from ltetrigger_swig import *  # noqa: F401,F403
 
 from .downlink_trigger_c import downlink_trigger_c, MIN_PSR_THRESHOLD  # noqa: E402,F401

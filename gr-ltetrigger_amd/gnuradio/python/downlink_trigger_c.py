@@ -7,7 +7,7 @@ the test suite exercises.
 """
 from gnuradio import blocks, gr
 
-from . import ltetrigger_python as _blocks
+from . import blocks_module as _blocks  # pybind11 or SWIG, resolved once in __init__.py
 
 MIN_PSR_THRESHOLD = 1.5  # the reference clamps here: lower thresholds crashed its srsLTE calls
 
@@ -18,7 +18,8 @@ class downlink_trigger_c(gr.hier_block2):
                                 gr.io_signature(1, 1, gr.sizeof_gr_complex), gr.io_signature(0, 0, 0))
         self.psr_threshold = max(psr_threshold, MIN_PSR_THRESHOLD)
         self.exit_on_success = exit_on_success
-        for port in ("track", "drop"):
+        for port in ("drop", "track"):  # both directions, as the reference does (python/downlink_trigger_c.py:47-48,55-56)
+            self.message_port_register_hier_in(port)
             self.message_port_register_hier_out(port)
         self._chains = []
         for n_id_2 in range(3):
