@@ -10,7 +10,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libltetrigger_hip.so")
+# (LTETRIGGER_HIP_LIB: another build of the same library, for A/B timing on one box -- tools/ab.sh; never a CPU stand-in)
+LIB_PATH = os.environ.get("LTETRIGGER_HIP_LIB") or os.path.join(_HERE, "libltetrigger_hip.so")
 
 LT_OK, LT_ERROR, LT_ERROR_INVALID_INPUTS = 0, -1, -2
 HALF_FRAME, SLOT, SYMBOL_SZ, CONV_LEN, NLAGS = 9600, 960, 128, 9728, 9726
@@ -346,9 +347,9 @@ class Batch:
 
     def set_window_cache(self, level):
         """Lag metrics formed in bulk: 0 = never, 1 = for the per-chain kernel, 2 = also for the scan rounds of small
-        batches, 3 (default) = 2 with the per-chain kernel's second pass only while chains ask for it, 4 = 3 with the
+        batches, 3 = 2 with the per-chain kernel's second pass only while chains ask for it, 4 (default) = 2 with the
         lag-metric streams of the chains that are not tracking (searches on any timing served from the cache: marginal
-        SNR; the oracle's records, but not the bits of levels 0..3) (lt_batch_set_window_cache)."""
+        SNR; the oracle's records, deterministic, but not the bits of levels 0..3) (lt_batch_set_window_cache)."""
         _check(lib().lt_batch_set_window_cache(self._h, int(level)), "lt_batch_set_window_cache")
 
     def cache_stats(self):

@@ -157,7 +157,8 @@ struct lt_batch {
   void *d_slot_owner = nullptr;
   void *d_slot_pos = nullptr;
   int cache_slots = 0;
-  int use_cache = 3;         // lt_batch_set_window_cache (3 = 2 with the per-chain kernel's second pass on demand)
+  int cache_quota = 0;       // ... of which every chain owns this many for the per-chain kernel's requests
+  int use_cache = 4;         // lt_batch_set_window_cache (4 = lag-metric streams for untracked chains; deterministic since round 5)
   void *d_cp = nullptr;      // per-record scratch (CP metrics, work list), [n_channels*3][rec_cap] x per_record_scratch_bytes()
   lt_cf32 *d_hist[2] = {nullptr, nullptr}; // streaming: the samples in front of the next chunk, [n_channels][hist_cap]
   int hist_sel = 0;
@@ -530,10 +531,15 @@ int64_t lt_batch_record_capacity(int64_t n_samples)
 }
 
 namespace {
-// Window cache: room for every chain's windows of a run, up to 16384 slots of 43 KB (705 MB at most; a small batch
-// scans from the cache: its rounds list windows ahead of chains that may leave them early, up to three times what a
-// chain ends up searching).  Allocated by lt_batch_create and by lt_batch_set_window_cache(1 | 2), freed by
+// Window cache: every chain has slots of its own (43 KB each: one window's lag metric, or 10752 elements of a chain's lag-metric
+// stream) -- as many as the windows of a run of max_samples, 256 at most -- so that what a chain gets out of the cache never
+// depends on what the other chains of the launch asked for, or on the order they asked in (with one pool handed
+// out first come first served, which chains of a 150-chain batch got their stream at level 4 was decided by a race).  1.7 GB
+// for 64 channels x 1 s; a small batch scans from the cache and gets three times the windows (its rounds list windows ahead
+// of chains that may leave them early).  Beyond kCacheBudget the quota shrinks (what lies beyond a chain's slots goes through
+// the transforms, for every chain alike).  Allocated by lt_batch_create and by lt_batch_set_window_cache(1 ... 4), freed by
 // lt_batch_set_window_cache(0).  Failure is not an error: the batch then runs without a cache.
+constexpr int64_t kCacheBudget = 48ll << 30;
 void free_window_cache(lt_batch *b)
 {
   if (b->d_cache) (void)hipFree(b->d_cache);
@@ -543,14 +549,19 @@ void free_window_cache(lt_batch *b)
   b->d_slot_owner = nullptr;
   b->d_slot_pos = nullptr;
   b->cache_slots = 0;
+  b->cache_quota = 0;
 }
 void alloc_window_cache(lt_batch *b)
 {
   if (b->d_cache) return;
-  const size_t nchains = (size_t)b->n_channels * 3;
+  const int64_t nchains = (int64_t)b->n_channels * 3;
   const int64_t windows = b->max_samples / LT_HALF_FRAME_LEN + 2;
-  const int64_t per_chain = b->n_channels <= 4 ? 3 * windows + 16 : std::min<int64_t>(windows, lt::cache_max_per_chain());
-  b->cache_slots = (int)std::min<int64_t>((int64_t)nchains * per_chain, 16384);
+  int64_t quota = std::min<int64_t>(windows, lt::cache_max_per_chain());
+  quota = std::min<int64_t>(quota, kCacheBudget / lt::cache_slot_bytes() / nchains);
+  const int64_t per_chain = b->n_channels <= 4 ? std::max<int64_t>(3 * windows + 16, quota) : quota;
+  if (quota < 1 || nchains * per_chain > 0x7fffffff / 16) return;
+  b->cache_slots = (int)(nchains * per_chain);
+  b->cache_quota = (int)quota;
   hipError_t ce = hipMalloc(&b->d_cache, (size_t)b->cache_slots * (size_t)lt::cache_slot_bytes());
   if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_owner, (size_t)b->cache_slots * 2 * sizeof(int));
   if (ce == hipSuccess) ce = hipMalloc(&b->d_slot_pos, (size_t)b->cache_slots * sizeof(int64_t));
@@ -777,6 +788,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.slot_owner = b->d_slot_owner;
   R.slot_pos = b->d_slot_pos;
   R.slot_cap = b->cache_slots;
+  R.slot_quota = b->cache_quota;
   R.records_delay_us = b->records_delay_us;
   R.wait_hint = b->d_wait_hint;
   R.run_id = (int)((b->n_runs + 1) & 0x3fffffff);
@@ -786,9 +798,11 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   {
     const int asked = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[0] : 0;
     const int done = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[1] : 0;
-    // level 3 (the default): one pass until a chain has asked, then two passes while chains keep asking; levels 1 and 2:
-    // two passes always
-    R.two_pass = b->use_cache < 3 || !b->h_wait_hint || (asked > 0 && asked > done - 2);
+    // level 3: one pass until a chain has asked, then two passes while chains keep asking (the host's position relative to
+    // the device picks the path: timing only at this level, whose two paths give the same bits); levels 1, 2 and 4: two passes
+    // always -- at level 4 a search out of a stream and one through the transforms differ in the low bits of PSR, so which of
+    // the two a run takes is decided by the chains' state on the device alone (pass 0), never by the host's cue
+    R.two_pass = b->use_cache != 3 || !b->h_wait_hint || (asked > 0 && asked > done - 2);
     if (b->n_runs == 0x3fffffff && b->h_wait_hint) b->h_wait_hint[0] = b->h_wait_hint[1] = 0; // (the run numbers wrap)
   }
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);

@@ -55,6 +55,11 @@ struct ChainArgs {
   int *slot_next;      // slots handed out so far in this run (may run past slot_cap: the excess does not exist)
   int *launch_slots;   // ... those of them that pass 0 hands out (lt_metric_kernel's share of the work)
   int slot_cap;
+  int slot_quota;      // slots of the cache that are this chain's and nobody else's: [chain * slot_quota, (chain + 1) * slot_quota).
+                       // What a chain gets out of the cache is then a function of its own state alone -- not of the order in
+                       // which the workgroups of a launch reach an atomic --, and so are the bits of its records where the
+                       // cached form rounds differently from the transforms (level 4).  slot_owner / slot_pos stay a work list
+                       // in whatever order the chains came (lt_metric_kernel does not care)
   int pass;
   int *wait_hint;      // two words of pinned host memory (or null): [0] set to run_id by a chain that has enough searches ahead
   int run_id;          // of it to ask for the cache -- whether the run has one or not --, [1] by the kernel as such (pass 0):
@@ -434,20 +439,20 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
         if (st->pre_n > 0 && st->pre_pos < o) o = st->pre_pos;
         int64_t want = (last_start + kNLags - o + kStreamSlot - 1) / kStreamSlot;
         if (want > kCacheMaxPerChain) want = kCacheMaxPerChain;
-        if (tid == 0) s_sbase = atomicAdd(a.slot_next, (int)want);
-        __syncthreads();
-        const int base = s_sbase;
-        const int got = a.slot_cap - base < (int)want ? a.slot_cap - base : (int)want;
+        const int got = a.slot_quota < (int)want ? a.slot_quota : (int)want; // (beyond its slots: pass 1, through the transforms)
         if (got >= 2) {
+          if (tid == 0) s_sbase = atomicAdd(a.slot_next, got); // a place on the work list (never short: the quotas add up to slot_cap)
+          __syncthreads();
+          const int wi = s_sbase;
           for (int i = tid; i < got; i += NT) {
-            a.slot_owner[base + i] = make_int2(chain, -1 - i); // (second member negative: a slot of a stream)
-            a.slot_pos[base + i] = o + (int64_t)i * kStreamSlot;
+            a.slot_owner[wi + i] = make_int2(chain, -1 - i); // (second member negative: a slot of a stream)
+            a.slot_pos[wi + i] = o + (int64_t)i * kStreamSlot;
           }
           if (tid == 0) {
             atomicAdd(a.launch_slots, got);
             atomicAdd(a.slot_next + 3, 1); // diagnostics
             st->cache_pos = o;
-            st->cache_base = base;
+            st->cache_base = chain * a.slot_quota;
             st->cache_n = got;
             st->cache_stride = 0; // (0: a stream)
           }
@@ -458,20 +463,20 @@ template <bool kLean> __device__ __forceinline__ void chain_run(const ChainArgs 
     }
     if (a.cache && ahead >= kCacheMinSearches) {
       __shared__ int s_base;
-      if (tid == 0) s_base = atomicAdd(a.slot_next, (int)ahead);
-      __syncthreads();
-      const int base = s_base;
-      int got = a.slot_cap - base < (int)ahead ? a.slot_cap - base : (int)ahead;
+      const int got = a.slot_quota < (int)ahead ? a.slot_quota : (int)ahead;
       if (got >= kCacheMinSearches) {
+        if (tid == 0) s_base = atomicAdd(a.slot_next, got);
+        __syncthreads();
+        const int wi = s_base;
         for (int i = tid; i < got; i += NT) {
-          a.slot_owner[base + i] = make_int2(chain, i);
-          a.slot_pos[base + i] = first + (int64_t)i * stride * kHalfFrame;
+          a.slot_owner[wi + i] = make_int2(chain, i);
+          a.slot_pos[wi + i] = first + (int64_t)i * stride * kHalfFrame;
         }
         if (tid == 0) {
           atomicAdd(a.launch_slots, got);
           atomicAdd(a.slot_next + 3, 1); // diagnostics
           st->cache_pos = first;
-          st->cache_base = base;
+          st->cache_base = chain * a.slot_quota;
           st->cache_n = got;
           st->cache_stride = stride;
         }
@@ -863,6 +868,8 @@ struct MetricArgs {
   const int *launch_slots; // [n_before + 1]: slots handed out for the launches before this one, then for this one
   int n_before;
   int slot_cap;
+  int quota;               // > 0: the list's entry (chain, k) is stored in the chain's own slots, chain * quota + k (the per-chain
+                           // kernel's requests); 0: in the slot of its place on the list (the scan rounds of small batches)
   float *cache;
   const DeviceTables *tab;
 };
@@ -915,7 +922,9 @@ __global__ __launch_bounds__(64 * kMetricWaves) void lt_metric_kernel(MetricArgs
     strip_root_lags(ln, x, spec, tw, TW2, e);
     float met[kStripRegs];
     strip_metric(x, met);
-    float *out = a.cache + (size_t)slot * cache_slot_floats() + (size_t)strip * kCacheStripLags + ln;
+    const int k_own = __builtin_amdgcn_readfirstlane(owner.y);
+    const int store = a.quota > 0 ? chain * a.quota + (of_stream ? -1 - k_own : k_own) : slot;
+    float *out = a.cache + (size_t)store * cache_slot_floats() + (size_t)strip * kCacheStripLags + ln;
 #pragma unroll
     for (int r = 0; r < kStripRegs; ++r) out[64 * r] = met[r];
   }

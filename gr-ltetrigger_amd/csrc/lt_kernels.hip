@@ -675,7 +675,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     MetricArgs mm;
     mm.iq = iq; mm.ch_stride = R.ch_stride; mm.hist = hist; mm.hist_stride = R.hist_stride; mm.t0 = R.t0; mm.n = R.n;
     mm.hist_len = R.hist_len; mm.slot_owner = p.slot_owner; mm.slot_pos = p.slot_pos; mm.launch_slots = R.n_jobs + kCtrLaunchSlots;
-    mm.slot_cap = R.slot_cap; mm.cache = reinterpret_cast<float *>(R.cache); mm.tab = R.tab;
+    mm.slot_cap = R.slot_cap; mm.quota = 0; mm.cache = reinterpret_cast<float *>(R.cache); mm.tab = R.tab;
     const int metric_grid = 4 * (R.n_cus > 0 ? R.n_cus : 256);
     hipLaunchKernelGGL(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
@@ -762,10 +762,11 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.slot_next = R.n_jobs + kCtrSlots; // (cleared with the run's other counters by its first launch)
     c.launch_slots = R.n_jobs + kCtrLaunchSlots + kMaxRounds + 1; // (its own count: the rounds are over, their slots free)
     c.slot_cap = R.slot_cap;
+    c.slot_quota = R.slot_quota;
     c.pass = 0;
     c.wait_hint = R.wait_hint;
     c.run_id = R.run_id;
-    if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && R.cache_level >= 1 && R.two_pass)) c.cache = nullptr;
+    if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && c.slot_quota >= kCacheMinSearches && R.cache_level >= 1 && R.two_pass)) c.cache = nullptr;
     c.stream = R.stream && c.cache;
     hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     if (c.cache) {
@@ -773,7 +774,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       MetricArgs m;
       m.iq = iq; m.ch_stride = R.ch_stride; m.hist = hist; m.hist_stride = R.hist_stride; m.t0 = R.t0; m.n = R.n;
       m.hist_len = R.hist_len; m.slot_owner = c.slot_owner; m.slot_pos = c.slot_pos; m.launch_slots = c.launch_slots;
-      m.n_before = 0; m.slot_cap = c.slot_cap;
+      m.n_before = 0; m.slot_cap = c.slot_cap; m.quota = c.slot_quota;
       m.cache = c.cache; m.tab = R.tab;
       const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
       hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);

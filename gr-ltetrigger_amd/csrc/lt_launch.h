@@ -54,6 +54,7 @@ struct RunLaunch {
   void *slot_pos = nullptr;   // device, slot_cap x int64
   int cache_level = 2;        // 0 = no cache, 1 = the per-chain kernel's two passes, 2 = also the scan rounds of small batches
   int slot_cap = 0;
+  int slot_quota = 0;         // slots per chain for the per-chain kernel's requests (slot_quota * n_channels * 3 <= slot_cap)
   int records_delay_us = 0;   // diagnostics (lt_batch_debug_hold_records): the per-record kernels start this much later
   int *wait_hint = nullptr;   // device view of two words in pinned host memory: the number of the last run in which a chain had
                               // enough searches ahead of it to ask for the window cache, and of the last run the per-chain kernel ran in

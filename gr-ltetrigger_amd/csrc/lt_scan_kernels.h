@@ -460,8 +460,8 @@ struct PlanArgs {
   // first launch of a run only (first_round): counters to clear behind n_jobs, the one to leave alone, positions to 0
   int n_counters, keep_counter, rebase;
   // window cache for the scan rounds (small batches): every job's windows get slots, lt_metric_kernel fills them
-  // before the round's scan.  round_slots counts the slots asked for in this round, from 0 in every round (it may run
-  // past slot_cap).
+  // before the round's scan.  round_slots counts the slots handed out in this round, from 0 in every round (never past
+  // slot_cap).
   int cached;
   int2 *slot_owner;   // [slot_cap]: (chain, window index in its sequence)
   int64_t *slot_pos;  // [slot_cap]: the window's position
@@ -623,10 +623,18 @@ __device__ __forceinline__ ScanJob *plan_channel(const PlanArgs &a, int c)
   int base = -1;
   if (a.cached && total > 0) {
     // (from the round's own counter: a round's slots live until its scan, the next round starts at slot 0 again -- a long
-    // capture does not run out of them.  The counter may run past the capacity: a job that does not fit stays uncached, and
-    // so does every job after it -- the slots in use are always the first ones.)
-    base = atomicAdd(a.round_slots, total);
-    if (base + total > a.slot_cap) base = -1;
+    // capture does not run out of them.  The counter only ever counts slots that were handed out -- lt_metric_kernel takes
+    // its share of the work from it, and a slot nobody owns has no owner to read --: a job that does not fit leaves it
+    // alone and stays uncached; the slots in use are always the first ones.)
+    int seen = __hip_atomic_load(a.round_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (seen + total <= a.slot_cap) {
+      const int was = atomicCAS(a.round_slots, seen, seen + total);
+      if (was == seen) {
+        base = seen;
+        break;
+      }
+      seen = was;
+    }
   }
   job->cached = base >= 0;
 #pragma unroll

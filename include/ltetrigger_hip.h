@@ -196,13 +196,18 @@ int lt_batch_get_mode(lt_batch *b);
  * its interior lags out of the stream and forms the 253 edge lags (whose sums stop at the window's first or last sample)
  * directly.  Tracking chains keep their windows.  The stream's blocks round differently from a window's strips: level 4
  * matches the oracle under the same bar as every level (integer, index and flag fields equal, everything downstream of
- * the lag metric bit-exact, PSR / peak value within 1e-4) but NOT the bits of levels 0 to 3 -- and since it is the
- * host's cue that decides whether a run has the second pass at all, its low bits may differ from run to run.  Made for
- * sweeps at marginal SNR (bench.py's config5 leg); not the default.
- * Footprint: min(3 n_channels x windows of max_samples, 16384) slots of 43 008 bytes -- 705 MB at most --, allocated by
- * lt_batch_create, freed by level 0 and allocated again by 1 / 2 (if the memory cannot be had the batch runs as at level 0).
- * The slots of a scan round (levels 2 / 3, up to four channels) are free again after the round: a capture of any length
- * scans from the cache. */
+ * the lag metric bit-exact, PSR / peak value within 1e-4) but NOT the bits of levels 0 to 3.  It is deterministic: which
+ * of a run's searches come out of a stream is decided on the device from the chains' state alone (the per-chain kernel's
+ * first pass; both passes are always enqueued at this level -- when no chain asks, lt_metric_kernel and the second pass are
+ * two launches that end at once), and every chain has cache slots of its own, so the same capture through the same
+ * settings gives the same bytes every time (tests/test_gpu_stream.py).  Across SETTINGS that change which searches the scan
+ * rounds leave to the per-chain kernel (execution mode, round lengths, workgroup shape) the low bits of PSR may differ at
+ * this level; levels 0 to 3 are bit-identical across those too.  THE DEFAULT (since round 5).
+ * Footprint: every chain owns min(windows of max_samples, 256) slots of 43 008 bytes (1.7 GB for 64 channels x 1 s; at most
+ * 48 GB: beyond that the per-chain share shrinks and what lies behind a chain's slots goes through the transforms);
+ * batches of up to four channels three times the windows.  Allocated by lt_batch_create, freed by level 0 and allocated
+ * again by 1 ... 4 (if the memory cannot be had the batch runs as at level 0).  The slots of a scan round (levels >= 2, up to
+ * four channels) are free again after the round: a capture of any length scans from the cache. */
 int lt_batch_set_window_cache(lt_batch *b, int level);
 /* Diagnostics of the last run: stats[0] = windows asked for, [1] = searches of the second pass served from the cache,
  * [2] = searches of the second pass that went through the transforms, [3] = chains that waited for the cache,

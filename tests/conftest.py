@@ -24,6 +24,40 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Filled by pytest_sessionstart when the GPU tests are selected: the finished `python bench.py --gpus 2` child
+# (returncode, stdout, stderr, steps) for tests/test_gpu_bench_configs.py::test_two_ranks_share_one_gpu.
+REHEARSAL = {}
+
+
+def pytest_sessionstart(session):
+    """`-m gpu`: the rehearsal of the N > 1 path -- two ranks of bench.py sharing this box's one GPU -- runs HERE, to its
+    end, before any test of this process has touched the GPU: a process that has initialised the GPU must not start
+    programs that use it (on the GPU boxes that takes the machine down).  torch.cuda.device_count() does not initialise
+    it.  LT_SKIP_REHEARSAL=1 skips (the test then skips too)."""
+    expr = (session.config.getoption("markexpr", "") or "").replace(" ", "")
+    if "gpu" not in expr or "notgpu" in expr or os.environ.get("LT_SKIP_REHEARSAL"):
+        return
+    if getattr(session.config, "workerinput", None) is not None:  # (an xdist worker: the controller has done it)
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    import subprocess
+    steps = 3
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "2",
+           "--no-end-to-end", "--no-overlap-leg", "--no-steady-leg"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        REHEARSAL.update(returncode=p.returncode, stdout=p.stdout, stderr=p.stderr, steps=steps)
+    except subprocess.TimeoutExpired as e:
+        REHEARSAL.update(returncode=-1, stdout=str(e.stdout or ""), stderr="timeout: " + str(e.stderr or ""), steps=steps)
+
+
 def load_frame(name):
     fname, decim, expect = FIXTURES[name]
     x = np.fromfile(os.path.join(GOLDEN, "test_frames", fname), dtype=np.complex64)

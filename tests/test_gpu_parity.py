@@ -311,6 +311,7 @@ def test_scan_and_per_chain_kernel_give_identical_records(lt, oracle, frames_192
     res = []
     for mode, seg, groups in ((0, None, 0), (1, None, 0), (1, (2, 32), 1), (1, (1, 5), 2), (1, (64, 64), 3), (1, (128, 128), 3), (1, None, 1), (1, None, 2)):
         b = lt.Batch(iq.shape[0], n)
+        b.set_window_cache(3)  # (bit-identity ACROSS settings is levels 0..3's; level 4, the default, is deterministic per setting)
         b.set_mode(mode)
         b.set_scan_groups(groups)
         if seg:
@@ -461,11 +462,18 @@ def test_chain_random_scenes(lt, oracle, frames_192, seed):
     for c in range(3 * n_ch):
         assert_records_match(got[c], want[c], f"seed {seed} {kw} chain {c}")
     # the benchmark's workgroup shape (three strips; a batch this small runs with one) gives the same bits
-    b3 = lt.Batch(iq.shape[0], iq.shape[1], **kw)
-    b3.set_scan_groups(3)
-    b3.run_host(iq)
-    for c, r in enumerate(b3.collect()):
-        assert r.tobytes() == got[c].tobytes(), f"seed {seed} chain {c}: three strips per workgroup"
+    # (at level 3: bit-identity across workgroup shapes is levels 0..3's -- at level 4 the shape decides which searches the
+    # rounds leave to the streams, and those round differently)
+    shapes = []
+    for groups in (0, 3):
+        b3 = lt.Batch(iq.shape[0], iq.shape[1], **kw)
+        b3.set_window_cache(3)
+        b3.set_scan_groups(groups)
+        b3.run_host(iq)
+        shapes.append([r.copy() for r in b3.collect()])
+    for c in range(3 * n_ch):
+        assert shapes[1][c].tobytes() == shapes[0][c].tobytes(), f"seed {seed} chain {c}: three strips per workgroup"
+        assert_records_match(shapes[0][c], want[c], f"seed {seed} {kw} chain {c} (level 3)")
 
 
 @pytest.mark.parametrize("seed", [11, 12])
@@ -587,11 +595,12 @@ def test_window_cache_gives_the_same_records(lt, oracle, frames_192, mode):
     want = oracle.batch_run(iq, nthreads=8)
     for c in range(18):
         assert_records_match(out[1][c], want[c], f"chain {c}")
-    # level 3, the default: the per-chain kernel runs once, without the cache, until a chain has had enough searches ahead of
+    # level 3: the per-chain kernel runs once, without the cache, until a chain has had enough searches ahead of
     # it to ask (the kernel reports the run through pinned host memory), and in two passes while chains keep asking -- the
     # first run of a fresh batch is one pass, the runs after a collect (the host has seen the report) two; same records
     b = lt.Batch(6, iq.shape[1])
     b.set_mode(mode)
+    b.set_window_cache(3)
     seen = []
     for k in range(3):
         b.reset()

@@ -123,3 +123,40 @@ def test_stream_shorter_than_the_capture(lt, oracle, frames_192):
             assert stats[2] > 20, f"... and, behind their ends, through the transforms: {stats}"
         for c in range(9):
             assert_records_match(got[c], want[c], f"mode {mode} chain {c}")
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_level4_is_deterministic(lt, oracle, frames_192, mode):
+    """The same capture five times at level 4 (the default): byte-identical records -- on a fresh batch each time, on one
+    batch run again and again after lt_batch_reset, with the host far ahead of the device (nothing collected in between)
+    and right behind it (collected after every run).  Round 4's level 4 took the one-pass / two-pass decision from a word
+    of pinned host memory the kernel writes asynchronously and handed the cache's slots out first come first served:
+    both could change the low bits of PSR from run to run.  50 channels = 150 chains at marginal SNR, the case in which the
+    old pool ran short."""
+    base = [(frames_192[n][19200:38400], FIXTURES[n][2]["cell_id"]) for n in FIXTURES]
+    iq, _ = siggen.scan_channels(base, 50, 45 * 9600 + 333, snr_db=-1.0, cfo=True, seed0=7000)
+    runs = []
+    for k in range(3):  # fresh batches (the library's default level: 4)
+        b = lt.Batch(50, iq.shape[1])
+        b.set_mode(mode)
+        b.run_host(iq)
+        runs.append([r.copy() for r in b.collect()])
+        stats = b.cache_stats()
+        assert stats[3] > 20 and stats[1] > 500, f"the scene must send chains through their streams in the very first run: {stats}"
+        b.close()
+    b = lt.Batch(50, iq.shape[1])
+    b.set_mode(mode)
+    for k in range(3):  # one batch, collected after every run
+        b.reset()
+        b.run_host(iq)
+        runs.append([r.copy() for r in b.collect()])
+    for k in range(4):  # ... and with four runs enqueued before the host looks at anything
+        b.reset()
+        b.run_host(iq)
+    runs.append([r.copy() for r in b.collect()])
+    for k, other in enumerate(runs[1:]):
+        for c in range(150):
+            assert other[c].tobytes() == runs[0][c].tobytes(), f"run {k + 1} chain {c}"
+    want = oracle.batch_run(iq, nthreads=8)
+    for c in range(150):
+        assert_records_match(runs[0][c], want[c], f"chain {c}")
