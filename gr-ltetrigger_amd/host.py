@@ -9,7 +9,8 @@ import numpy as np
 from . import _binding
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "libgnuradio-ltetrigger-amd.so")
+# (LT_HOST_LIB: another build of the same library -- the AddressSanitizer one of `make asan`, tests/test_sanitizers.py)
+HOST_LIB_PATH = os.environ.get("LT_HOST_LIB") or os.path.join(_HERE, "libgnuradio-ltetrigger-amd.so")
 
 _hlib = None
 
@@ -41,6 +42,7 @@ def hlib():
     for f in ("ltr_add_cellstore", "ltr_add_message_debug", "ltr_add_null_sink", "ltr_add_probe", "ltr_run"):
         getattr(L, f).argtypes = [vp]
     L.ltr_run_timeout.argtypes = [vp, C.c_double]
+    L.ltr_run_threaded.argtypes = [vp, C.c_double]
     L.ltr_connect.argtypes = [vp, i32, i32]
     L.ltr_msg_connect.argtypes = [vp, i32, cp, i32, cp]
     for f in ("ltr_pss_max_psr", "ltr_pss_mean_psr", "ltr_pss_mean_cfo", "ltr_pss_psr_threshold",
@@ -231,6 +233,11 @@ class TopBlock:
         else:
             _id(hlib().ltr_msg_connect(self._h, src.id, src_port.encode(), dst.id, dst_port.encode()), "msg_connect")
 
-    def run(self, time_out=-1.0):
-        """Run to completion; time_out >= 0 bounds the wall time (tb.start(); sleep; tb.stop())."""
-        _id(hlib().ltr_run_timeout(self._h, float(time_out)), "run")
+    def run(self, time_out=-1.0, threaded=False):
+        """Run to completion; time_out >= 0 bounds the wall time (tb.start(); sleep; tb.stop()).  threaded: one thread per
+        block, as GNU Radio's scheduler runs the reference (ctypes releases the GIL: other Python threads may poll the
+        getters meanwhile)."""
+        if threaded:
+            _id(hlib().ltr_run_threaded(self._h, float(time_out)), "run")
+        else:
+            _id(hlib().ltr_run_timeout(self._h, float(time_out)), "run")

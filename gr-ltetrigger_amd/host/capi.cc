@@ -115,6 +115,7 @@ int ltr_msg_connect(ltr_tb *tb, int src, const char *sp, int dst, const char *dp
 }
 int ltr_run(ltr_tb *tb) { LTR_TRY(tb->tb.run(); return 0;, -1) }
 int ltr_run_timeout(ltr_tb *tb, double s) { LTR_TRY(tb->tb.run(s); return 0;, -1) }
+int ltr_run_threaded(ltr_tb *tb, double s) { LTR_TRY(tb->tb.run_threaded(s); return 0;, -1) }
 
 float ltr_pss_max_psr(ltr_tb *tb, int id) { LTR_TRY(return tb->get<gr::ltetrigger::pss>(id)->max_psr();, -1.f) }
 float ltr_pss_mean_psr(ltr_tb *tb, int id) { LTR_TRY(return tb->get<gr::ltetrigger::pss>(id)->mean_psr();, -1.f) }

@@ -35,6 +35,9 @@ int ltr_connect(ltr_tb *tb, int src, int dst);
 int ltr_msg_connect(ltr_tb *tb, int src, const char *src_port, int dst, const char *dst_port);
 int ltr_run(ltr_tb *tb);
 int ltr_run_timeout(ltr_tb *tb, double max_seconds); /* < 0: no limit */
+/* the same flowgraph under a thread-per-block scheduler (GNU Radio's default): callable while other threads poll the
+ * ltr_pss_* getters, ltr_msgdebug_count and the ltr_cellstore_* calls of the same top block */
+int ltr_run_threaded(ltr_tb *tb, double max_seconds);
 
 float ltr_pss_max_psr(ltr_tb *tb, int id);
 float ltr_pss_mean_psr(ltr_tb *tb, int id);

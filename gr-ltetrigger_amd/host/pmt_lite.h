@@ -5,6 +5,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <utility>
@@ -51,6 +52,8 @@ inline const pmt_t &false_()
 inline pmt_t intern(const std::string &s)
 {
   static std::map<std::string, pmt_t> table;
+  static std::mutex mu; // (blocks intern keys from their own threads: mib_impl::pack_cell, the cellstore's handler)
+  std::lock_guard<std::mutex> lock(mu);
   auto it = table.find(s);
   if (it != table.end()) return it->second;
   auto p = std::make_shared<pmt_base>();

@@ -78,8 +78,11 @@ void pss_impl::score_miss() // reset_score, lib/pss_impl.cc:129-152
   d_timer = 0; // search again on the very next half-frame
   d_is_tracking = false;
   lt_pss_reset(d_pss);
-  d_psr_count = 0;
-  d_cfo_count = 0;
+  {
+    std::lock_guard<std::mutex> l(d_ring_mu);
+    d_psr_count = 0;
+    d_cfo_count = 0;
+  }
   lt_cfo_set_last_freq(d_cfo, 0.f);
   d_tracking_lost = true; // tag the next emitted half-frame
 }
@@ -96,15 +99,16 @@ int pss_impl::general_work(int noutput_items, gr_vector_int &ninput_items, gr_ve
     const int pos = lt_pss_find_pss(d_pss, in, &d_psr);
     if (pos < 0) throw std::runtime_error(std::string("lt_pss_find_pss: ") + lt_last_error());
     d_peak_pos = pos;
+    std::lock_guard<std::mutex> l(d_ring_mu);
     d_psr_ring[d_psr_count++ % ring_size] = d_psr;
   } else {
     --d_timer;
   }
 
-  const bool hit = d_psr > d_psr_threshold;
+  const bool hit = d_psr > psr_threshold();
   if (hit) score_hit();
   else score_miss();
-  if (d_psr > d_psr_max) d_psr_max = d_psr;
+  if (d_psr > max_psr()) d_psr_max.store(d_psr, std::memory_order_relaxed);
 
   if (!hit && !d_tracking_lost) { // nothing to see: drop this half-frame
     consume_each(half_frame_length);
@@ -127,7 +131,10 @@ int pss_impl::general_work(int noutput_items, gr_vector_int &ninput_items, gr_ve
     float cfo = 0.f;
     if (lt_pss_cfo_compute(d_pss, out + (slot_length - symbol_sz), &cfo))
       throw std::runtime_error(std::string("lt_pss_cfo_compute: ") + lt_last_error());
-    d_cfo_ring[d_cfo_count++ % ring_size] = cfo;
+    {
+      std::lock_guard<std::mutex> l(d_ring_mu);
+      d_cfo_ring[d_cfo_count++ % ring_size] = cfo;
+    }
     if (lt_cfo_correct(d_cfo, out, out, -mean_cfo() / symbol_sz))
       throw std::runtime_error(std::string("lt_cfo_correct: ") + lt_last_error());
     // srslte_pss_chest (lib/pss_impl.cc:206-209) filled a buffer nobody reads: not reproduced

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 
 namespace gr {
 
@@ -19,7 +20,9 @@ void basic_block::message_port_pub(pmt::pmt_t port, pmt::pmt_t msg)
 void basic_block::post(pmt::pmt_t port, pmt::pmt_t msg)
 {
   auto it = d_in_ports.find(port.get());
-  if (it != d_in_ports.end() && it->second) it->second(msg);
+  if (it == d_in_ports.end() || !it->second) return;
+  std::lock_guard<std::mutex> lock(d_msg_mu);
+  it->second(msg);
 }
 
 // ---------------------------------------------------------------- block
@@ -77,10 +80,29 @@ void block::get_tags_in_window(std::vector<tag_t> &v, unsigned which, uint64_t r
     if (pmt::eq(t.key, key)) v.push_back(t);
 }
 
+// (called on the upstream's thread)
 void block::accept(const gr_complex *items, size_t n, const std::vector<tag_t> &tags)
 {
-  d_in.insert(d_in.end(), items, items + n);
-  d_in_tags.insert(d_in_tags.end(), tags.begin(), tags.end());
+  std::lock_guard<std::mutex> lock(d_mu);
+  d_inbox.insert(d_inbox.end(), items, items + n);
+  d_inbox_tags.insert(d_inbox_tags.end(), tags.begin(), tags.end());
+  d_backlog.fetch_add(n, std::memory_order_relaxed);
+}
+
+// (on the block's own thread: whatever the upstream has handed over since the last step)
+void block::take_inbox()
+{
+  // "the upstream is done" is read BEFORE the inbox is emptied: its last items were handed over before it said so
+  if (d_upstream && d_upstream->d_done.load(std::memory_order_acquire)) d_upstream_done = true;
+  std::lock_guard<std::mutex> lock(d_mu);
+  if (!d_inbox.empty()) {
+    d_in.insert(d_in.end(), d_inbox.begin(), d_inbox.end());
+    d_inbox.clear();
+  }
+  if (!d_inbox_tags.empty()) {
+    d_in_tags.insert(d_in_tags.end(), d_inbox_tags.begin(), d_inbox_tags.end());
+    d_inbox_tags.clear();
+  }
 }
 
 bool block::step()
@@ -90,7 +112,7 @@ bool block::step()
     bool all_done = true;
     for (block *d : d_downstream) all_done = all_done && d->d_done;
     if (all_done) {
-      d_done = true;
+      d_done.store(true, std::memory_order_release);
       return true;
     }
     for (block *d : d_downstream) // back-pressure
@@ -100,6 +122,7 @@ bool block::step()
   int noutput = d_output_multiple > 1 ? d_output_multiple : kDefaultChunk;
   int64_t avail = 0;
   d_draining = false;
+  if (!source) take_inbox();
   if (!source) {
     avail = d_in_abs0 + (int64_t)d_in.size() - d_nread;
     const int64_t have = avail + (int64_t)history() - 1;
@@ -124,11 +147,11 @@ bool block::step()
       // end of a finite stream: run on what is left if the default contract (noutput new items) holds
       noutput = d_output_multiple > 1 ? d_output_multiple : 1;
       if (avail < noutput) {
-        d_done = true;
+        d_done.store(true, std::memory_order_release);
         return true;
       }
       if (d_output_multiple <= 1) {
-        d_done = true; // rate-changing blocks without an output multiple cannot use a partial tail
+        d_done.store(true, std::memory_order_release); // rate-changing blocks without an output multiple cannot use a partial tail
         return true;
       }
       d_draining = true;
@@ -152,6 +175,7 @@ bool block::step()
 
   if (!source && d_consumed > 0) {
     d_nread += d_consumed;
+    d_backlog.fetch_sub((size_t)d_consumed, std::memory_order_relaxed);
     const int64_t keep_from = d_nread - (int64_t)(history() - 1);
     if (keep_from > d_in_abs0) {
       d_in.erase(d_in.begin(), d_in.begin() + (size_t)(keep_from - d_in_abs0));
@@ -161,14 +185,14 @@ bool block::step()
                                    [&](const tag_t &t) { return (int64_t)t.offset < d_nread; }),
                     d_in_tags.end());
   }
-  if (ret == WORK_DONE) {
-    d_done = true;
-    return true;
-  }
   if (ret > 0) {
     for (block *d : d_downstream)
       if (!d->d_done) d->accept(d_out.data(), (size_t)ret, out_tags);
     d_nwritten += (uint64_t)ret;
+  }
+  if (ret == WORK_DONE) {
+    d_done.store(true, std::memory_order_release); // (after the hand-over: a downstream that sees it finds everything in its inbox)
+    return true;
   }
   return ret > 0 || d_consumed > 0;
 }
@@ -238,6 +262,73 @@ void top_block::run(double max_seconds)
   }
 }
 
+// ---------------------------------------------------------------- thread-per-block scheduler
+void top_block::wake_all()
+{
+  {
+    std::lock_guard<std::mutex> lock(d_wake_mu);
+    ++d_wake_gen;
+  }
+  d_wake.notify_all();
+}
+
+void block::thread_main(top_block *tb)
+{
+  for (;;) {
+    uint64_t gen;
+    {
+      std::lock_guard<std::mutex> lock(tb->d_wake_mu);
+      gen = tb->d_wake_gen;
+    }
+    if (tb->d_stop.load(std::memory_order_acquire) || d_done.load(std::memory_order_acquire)) break;
+    bool moved = false;
+    while (!tb->d_stop.load(std::memory_order_acquire) && step()) moved = true;
+    if (moved) {
+      tb->wake_all();
+      continue;
+    }
+    // nothing to do until a neighbour has moved: wait for the next signal (a bounded wait: a signal sent between the
+    // generation read above and here is seen through the generation, one that the bookkeeping missed through the timeout)
+    std::unique_lock<std::mutex> lock(tb->d_wake_mu);
+    // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be pthread_cond_clockwait, which GCC 11's
+    // ThreadSanitizer does not intercept -- it then misses the unlock inside the wait and reports a double lock)
+    tb->d_wake.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(2),
+                          [&] { return tb->d_wake_gen != gen || tb->d_stop.load(std::memory_order_acquire); });
+  }
+  tb->wake_all();
+}
+
+void top_block::run_threaded(double max_seconds)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  d_stop.store(false, std::memory_order_release);
+  std::vector<std::thread> threads;
+  std::vector<std::exception_ptr> errors(d_blocks.size());
+  for (size_t i = 0; i < d_blocks.size(); ++i)
+    threads.emplace_back([this, i, &errors] {
+      try {
+        d_blocks[i]->thread_main(this);
+      } catch (...) {
+        errors[i] = std::current_exception();
+        d_stop.store(true, std::memory_order_release);
+        wake_all();
+      }
+    });
+  for (;;) {
+    bool all_done = true;
+    for (auto &b : d_blocks) all_done = all_done && b->done();
+    if (all_done || d_stop.load(std::memory_order_acquire)) break;
+    if (max_seconds >= 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= max_seconds) break;
+    std::unique_lock<std::mutex> lock(d_wake_mu);
+    d_wake.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(5));
+  }
+  d_stop.store(true, std::memory_order_release);
+  wake_all();
+  for (auto &t : threads) t.join();
+  for (auto &e : errors)
+    if (e) std::rethrow_exception(e);
+}
+
 // ---------------------------------------------------------------- stock blocks
 namespace blocks {
 
@@ -305,7 +396,10 @@ null_sink::null_sink()
 message_debug::message_debug() : basic_block("message_debug")
 {
   message_port_register_in(pmt::mp("store"));
-  set_msg_handler(pmt::mp("store"), [this](pmt::pmt_t m) { d_msgs.push_back(m); });
+  set_msg_handler(pmt::mp("store"), [this](pmt::pmt_t m) {
+    std::lock_guard<std::mutex> l(d_mu);
+    d_msgs.push_back(m);
+  });
 }
 
 } // namespace blocks

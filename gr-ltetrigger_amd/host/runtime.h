@@ -2,14 +2,21 @@
 // both containers: the block sources in this directory are written against the
 // GNU Radio API (gr::block / gr::sync_block, general_work / work, set_history,
 // set_output_multiple, stream tags, message ports) and this header supplies just enough of it to
-// run them: single-threaded, complex-float streams only, one input and one output per block.
+// run them: complex-float streams only, one input and one output per block.  Two schedulers: run() steps the blocks in
+// flowgraph order on the caller's thread (the call sequence of every block is then a function of the input alone: what
+// the parity tests use); run_threaded() gives every block a thread of its own, as GNU Radio's thread-per-block
+// scheduler does -- work() of different blocks runs concurrently, getters are polled from foreign threads
+// (lib/pss_impl.h:95-100), message handlers run under the receiving block's message lock.
 // Semantics follow SURVEY Appendix A.7.
 #pragma once
+#include <atomic>
 #include <complex>
+#include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -57,6 +64,7 @@ private:
   std::string d_name;
   std::map<const pmt::pmt_base *, std::vector<std::pair<basic_block *, pmt::pmt_t>>> d_out_ports;
   std::map<const pmt::pmt_base *, msg_handler_t> d_in_ports;
+  std::mutex d_msg_mu; // a block's message handlers run one at a time, whichever thread posts (GNU Radio: on the block's own thread)
 };
 typedef std::shared_ptr<basic_block> basic_block_sptr;
 
@@ -87,7 +95,7 @@ public:
   void get_tags_in_range(std::vector<tag_t> &v, unsigned which_input, uint64_t abs_start, uint64_t abs_end);
   void set_tag_propagation_policy(tag_propagation_policy_t p) { d_tpp = p; }
   tag_propagation_policy_t tag_propagation_policy() const { return d_tpp; }
-  bool done() const { return d_done; }
+  bool done() const { return d_done.load(std::memory_order_acquire); }
   // true while the scheduler calls general_work with less input than forecast() asked for
   // because the upstream has finished (end of a finite capture)
   bool draining() const { return d_draining; }
@@ -99,24 +107,31 @@ private:
   friend class top_block;
   bool step();
   void accept(const gr_complex *items, size_t n, const std::vector<tag_t> &tags);
-  size_t backlog() const { return (size_t)((int64_t)(d_in_abs0 + (int64_t)d_in.size()) - d_nread); }
+  void take_inbox();
+  size_t backlog() const { return d_backlog.load(std::memory_order_relaxed); }
+  void thread_main(top_block *tb);
 
   io_signature::sptr d_in_sig, d_out_sig;
   unsigned d_history = 1;
   int d_output_multiple = 1;
   tag_propagation_policy_t d_tpp = TPP_ALL_TO_ALL;
-  // input side
+  // input side.  d_in / d_in_tags belong to the thread that steps the block; what the upstream hands over lands in the inbox
+  // (under d_mu, from the upstream's thread) and is moved across at the top of a step.
   std::vector<gr_complex> d_in; // d_in[0] is absolute item d_in_abs0 (negative while history is zeros)
   int64_t d_in_abs0 = 0;
   int64_t d_nread = 0;
   std::vector<tag_t> d_in_tags;
   bool d_upstream_done = false;
+  std::mutex d_mu;
+  std::vector<gr_complex> d_inbox;
+  std::vector<tag_t> d_inbox_tags;
+  std::atomic<size_t> d_backlog{0}; // items handed over and not yet consumed
   // output side
   uint64_t d_nwritten = 0;
   std::vector<tag_t> d_new_tags;
   std::vector<gr_complex> d_out;
   int d_consumed = 0;
-  bool d_done = false;
+  std::atomic<bool> d_done{false};
   bool d_draining = false;
   block *d_upstream = nullptr;
   std::vector<block *> d_downstream;
@@ -142,11 +157,22 @@ public:
   // run to completion, or (max_seconds >= 0) until that much wall time has passed -- tb.start();
   // sleep; tb.stop(); tb.wait() of examples/cell_search_file.py:101-111
   void run(double max_seconds = -1.0);
+  // the same flowgraph with one thread per block (GNU Radio's default scheduler): returns when every block is done, or
+  // after max_seconds.  An exception thrown by a block's work ends the run and is rethrown here.
+  void run_threaded(double max_seconds = -1.0);
 
 private:
+  friend class block;
   std::vector<block_sptr> d_blocks; // in connection order; sources first by construction
   std::vector<basic_block_sptr> d_keepalive;
   void add(block_sptr b);
+  // run_threaded: one condition variable for the whole flowgraph -- a block that cannot step waits on it, every step that
+  // moved items (or finished a block) signals it
+  std::mutex d_wake_mu;
+  std::condition_variable d_wake;
+  uint64_t d_wake_gen = 0;
+  std::atomic<bool> d_stop{false};
+  void wake_all();
 };
 
 // ---- the handful of stock blocks the reference's flowgraphs use
@@ -198,11 +224,12 @@ class message_debug : public basic_block
 public:
   typedef std::shared_ptr<message_debug> sptr;
   static sptr make() { return sptr(new message_debug); }
-  int num_messages() const { return (int)d_msgs.size(); }
-  pmt::pmt_t get_message(int i) const { return d_msgs.at(i); }
+  int num_messages() const { std::lock_guard<std::mutex> l(d_mu); return (int)d_msgs.size(); }
+  pmt::pmt_t get_message(int i) const { std::lock_guard<std::mutex> l(d_mu); return d_msgs.at(i); }
 
 private:
   message_debug();
+  mutable std::mutex d_mu; // (read from the application's thread while the flowgraph runs)
   std::vector<pmt::pmt_t> d_msgs;
 };
 

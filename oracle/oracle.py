@@ -76,8 +76,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_LIB_PATH)
+    path = os.environ.get("LT_ORACLE_LIB")  # (the sanitizer build of gr-ltetrigger_amd/Makefile `asan`: tests/test_sanitizers.py)
+    if not path:
+        build()
+        path = _LIB_PATH
+    L = C.CDLL(path)
     vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     L.orc_pss_create.restype = vp
     L.orc_pss_create.argtypes = [i32]

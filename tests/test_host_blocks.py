@@ -192,3 +192,64 @@ def test_cell_search_file_cli(lt, capsys, tmp_path):
     assert [json.loads(r) for r in res] == [{"status": "NOT_FOUND"}]
     with pytest.raises(SystemExit):
         mod.main(mod.parse_args([f, "-s", "2M"]))
+
+
+def test_thread_per_block_scheduler_gives_the_same_messages_and_streams(lt, oracle):
+    """GNU Radio runs the reference one thread per block, and applications poll the pss getters and the cellstore from
+    their own thread meanwhile (lib/pss_impl.h:95-100; examples/rtlsdr_ltetrigger.grc:751-838).  The same flowgraphs under
+    the in-repo runtime's thread-per-block scheduler (top_block::run_threaded: twelve block threads per trigger, each pss /
+    sss with its own C-ABI handles and streams) while a Python thread polls: the pss / sss output streams and tags, the
+    track / drop messages and the cellstore are those of the single-threaded run."""
+    import threading
+    x, _, _ = load_frame("6prb")
+    rng = np.random.default_rng(5)
+    sig = siggen.loop_to(x, 170 * 9600).copy()
+    sig[30 * 9600:100 * 9600] = siggen.awgn(rng, 70 * 9600, 0.5)
+
+    def run(threaded):
+        tb = lt.TopBlock()
+        src = tb.vector_source(sig)
+        trig = lt.downlink_trigger_c(tb, 4, exit_on_success=False)
+        store = tb.cellstore()
+        tracks, drops = tb.message_debug(), tb.message_debug()
+        tb.connect(src, trig)
+        tb.msg_connect(trig, "track", store, "track")
+        tb.msg_connect(trig, "drop", store, "drop")
+        tb.msg_connect(trig, "track", tracks, "store")
+        tb.msg_connect(trig, "drop", drops, "store")
+        # a second consumer of the same source: one chain's streams, tapped behind pss and behind sss
+        pss, sss = tb.pss(0, 4.0), tb.sss(0)
+        p1, p2 = tb.probe(), tb.probe()
+        tb.connect(src, pss, p1)
+        tb.connect(pss, sss, p2)
+        stop, polls = threading.Event(), [0]
+
+        def poll():
+            while not stop.is_set():
+                for p in trig.pss + [pss]:
+                    p.max_psr(), p.mean_psr(), p.mean_cfo(), p.tracking_score(), p.psr_threshold()
+                store.tracking(), store.cells(), store.latest_cell(), tracks.num_messages()
+                polls[0] += 1
+        t = threading.Thread(target=poll)
+        if threaded:
+            t.start()
+        tb.run(threaded=threaded)
+        stop.set()
+        if threaded:
+            t.join()
+        strip = lambda m: {k: v for k, v in m.items() if k != "tracking_start_time"}
+        return {"tracks": [strip(tracks.get_message(i)) for i in range(tracks.num_messages())],
+                "drops": [strip(drops.get_message(i)) for i in range(drops.num_messages())],
+                "cells": [strip(c) for c in store.cells()], "pss": p1.items(), "sss": p2.items(),
+                "tags1": sorted((t["offset"], t["key"]) for t in p1.tags()),
+                "tags2": sorted((t["offset"], t["key"], str(t["value"])) for t in p2.tags()),
+                "getters": (pss.max_psr(), pss.mean_psr(), pss.mean_cfo(), pss.tracking_score()), "polls": polls[0]}
+    ref = run(False)
+    assert len(ref["tracks"]) == 2 and len(ref["drops"]) == 1 and ref["pss"].size > 50 * 9600
+    for rep in range(2):
+        got = run(True)
+        assert got["polls"] > 0
+        for k in ("tracks", "drops", "cells", "tags1", "tags2", "getters"):
+            assert got[k] == ref[k], f"threaded run {rep}: {k}"
+        for k in ("pss", "sss"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), f"threaded run {rep}: {k} stream"
