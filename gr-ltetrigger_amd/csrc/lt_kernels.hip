@@ -562,7 +562,7 @@ constexpr int kCachedScanMaxChannels = 4; // batches up to this size scan from t
 
 int call_reach() { return kCallReach; }
 int scan_job_bytes() { return (int)sizeof(ScanJob); }
-int scan_parts_bytes_per_chain() { return (int)(sizeof(StripPartial) * kStrips * kScanMaxRound); }
+int scan_parts_bytes_per_chain() { return (int)((sizeof(StripHead) + sizeof(float) * kRowLags) * kStrips * kScanMaxRound); } // heads, then rows
 int scan_max_round() { return kScanMaxRound; }
 int scan_max_rounds() { return kMaxRounds; }
 // the run's counters: job counters of every round, the two work lists', the window cache's slot counter with six
@@ -596,7 +596,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
   const v2f *hist = reinterpret_cast<const v2f *>(R.hist);
   ChainState *state = reinterpret_cast<ChainState *>(R.state);
   ScanJob *jobs = reinterpret_cast<ScanJob *>(R.jobs);
-  StripPartial *parts = reinterpret_cast<StripPartial *>(R.parts);
+  // (what the scan's strips leave for the resolver: every chain's heads first, the rows behind them)
+  StripHead *parts = reinterpret_cast<StripHead *>(R.parts);
+  float *part_rows = parts ? reinterpret_cast<float *>(parts + (size_t)n_chains * kScanMaxRound * kStrips) : nullptr;
   const int64_t t1 = R.t0 + R.n;
   // ---- rounds of plan, scan, resolve.  An idle chain needs one round per `seg_len` windows; a chain that fires
   // needs a few more (a round ends for it where it re-aligns, where tracking starts, where it is lost).  Rounds
@@ -612,10 +614,10 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     p.track_after = R.track_after; p.track_every = R.track_every; p.call_reach = kCallReach;
     ScanArgs s;
     s.iq = iq; s.ch_stride = R.ch_stride; s.hist = hist; s.hist_stride = R.hist_stride; s.t0 = R.t0; s.n = R.n;
-    s.hist_len = R.hist_len; s.state = state; s.parts = parts;
+    s.hist_len = R.hist_len; s.state = state; s.heads = parts; s.rows = part_rows;
     s.tab = R.tab; s.prof = nullptr;
     ResolveArgs q;
-    q.state = state; q.parts = parts; q.recs = R.recs; q.rec_cap = R.rec_cap;
+    q.state = state; q.heads = parts; q.rows = part_rows; q.recs = R.recs; q.rec_cap = R.rec_cap;
     q.rec_count = R.rec_count; q.t1 = t1; q.flush = R.flush; q.call_reach = kCallReach; q.psr_threshold = R.psr_threshold;
     q.track_after = R.track_after; q.track_every = R.track_every;
     const int seg_first = R.seg_first < 1 ? 1 : R.seg_first > kScanMaxRound ? kScanMaxRound : R.seg_first;

@@ -225,6 +225,56 @@ __device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, S
   strip_lobe(e, s, lane, k, out);
 }
 
+// ---- the deferred form (scan rounds, round 5).  Eleven of a window's twelve lobe walks are thrown away: only the strip that
+// holds the window's peak needs its lobe.  A root wave of the scan therefore stops after the strip's maximum: it writes
+//   StripHead  m1, p1 -- the maximum over the owned lags and its lag --, far = the maximum over the owned lags OUTSIDE the 64
+//              lags around p1, a0 (strip 0: the average of lag 0), 16 bytes;
+//   a row      the 64 lags p1 - 32 .. p1 + 31 themselves (halo lags included: the walk may cross the strip's boundary), 256 bytes
+// and the resolver (one lane per window) walks the lobe of the ONE strip that holds the window's maximum, in the oracle's own
+// terms (oracle/lte_oracle.c:300-316): side-lobe maximum = the largest value outside [lb, ub) = max over the peak strip's far
+// and the owned lags of its row outside the lobe, and over the other strips' maxima -- or, for a neighbour whose maximum lies
+// on the slope of this lobe, over ITS far and the owned lags of ITS row outside the lobe (every lag the lobe covers in the
+// neighbour lies within 30 lags of the neighbour's maximum: both sit between the strip boundary and the lobe's end).
+struct StripHead {
+  float m1;
+  int32_t p1f;   // p1 | kHeadNoMax
+  float far;
+  float a0;
+};
+static_assert(sizeof(StripHead) == 16, "StripHead layout");
+constexpr int32_t kHeadNoMax = 1 << 30; // no maximum found (a NaN in the average): the window goes to the exact path
+constexpr int kRowLags = 64;
+
+// -> the strip's head (wave-uniform), this lane's value of the row and its place in it (index i <-> lag p1 - 32 + i)
+__device__ __forceinline__ void strip_head_row(const ema_t &e, int s, int lane, StripHead &h, float &row, int &idx)
+{
+  StripPeak k;
+  strip_peak(e, s, lane, k);
+  const int own13_end = (s == kStrips - 1) ? (kNLags - (kStripPitch * (kStrips - 1) - kStripHalo) - 64 * 13)
+                                           : (kStripHalo + kStripPitch - 64 * 13);
+  const uint64_t halo0 = (1ull << kStripHalo) - 1ull, halo13 = ~((1ull << own13_end) - 1ull);
+  const int l_p = k.l_p, r_p = k.r_p;
+  const int r_b = (l_p < 32) ? (r_p > 0 ? r_p - 1 : 1) : (r_p < kStripRegs - 1 ? r_p + 1 : kStripRegs - 2);
+  const float rowA = e[r_p], rowB = e[r_b]; // (run-time register index, wave-uniform)
+  const int d = lane - l_p;
+  const int off = ((d + 32) & 63) - 32;
+  const bool use_b = d != off;
+  row = use_b ? rowB : rowA;
+  const uint64_t outA = r_p == 0 ? halo0 : r_p == kStripRegs - 1 ? halo13 : 0ull;
+  const uint64_t outB = r_b == 0 ? halo0 : r_b == kStripRegs - 1 ? halo13 : 0ull;
+  const uint64_t wrapped = __ballot(use_b);
+  const uint64_t sits_out = (wrapped & outB) | (~wrapped & outA);
+  float row_own;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(row_own) : "v"(row), "v"(-FLT_MAX), "s"(sits_out));
+  // outside the row a lane contributes its maximum -- or its second largest value where its maximum IS its row value
+  const float far_lane = (row_own == k.m) ? k.m2 : k.m;
+  h.m1 = k.M1;
+  h.p1f = k.p1 | (k.flags ? kHeadNoMax : 0);
+  h.far = wave_max_dpp(far_lane);
+  h.a0 = (s == 0) ? rlane(e[0], kStripHalo) : 0.f;
+  idx = off + 32;
+}
+
 struct WindowResult {
   int peak_pos;
   float peak_value;
@@ -349,6 +399,98 @@ __device__ __forceinline__ WindowResult resolve_window_global(const StripPartial
   // the right one when the lobe reaches lag 9726 (avg[9726..9727] = 0)
   float sl = out;
   if (w.peak_pos <= 2) sl = parts[0].a0;
+  const float sr = (ub >= kNLags) ? 0.f : out;
+  const float side = sl > sr ? sl : sr;
+  w.psr = w.peak_value / side;
+  return w;
+}
+
+// The deferred form's resolver, one lane per window: heads = the window's 12 StripHeads, rows = its 12 rows (global memory).
+__device__ __forceinline__ bool lag_owned(int s, int lag) { return lag >= kStripPitch * s && lag < kStripPitch * (s + 1) && lag < kNLags; }
+// maximum over strip s's far and the owned lags of its row outside [lb, ub)  (the rare path: a neighbour on the lobe's slope)
+__device__ __forceinline__ float strip_outside_lobe(const StripHead *__restrict__ heads, const float *__restrict__ rows, int s, int lb, int ub)
+{
+  const StripHead h = heads[s];
+  const int p = h.p1f & ~kHeadNoMax;
+  float v = h.far;
+#pragma unroll 1
+  for (int i = 0; i < kRowLags; ++i) {
+    const int lag = p - 32 + i;
+    const float x = rows[s * kRowLags + i];
+    if (lag_owned(s, lag) && (lag < lb || lag >= ub) && x > v) v = x;
+  }
+  return v;
+}
+__device__ __forceinline__ WindowResult resolve_window_deferred(const StripHead *__restrict__ heads, const float *__restrict__ rows)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f h[kStrips];
+#pragma unroll
+  for (int s = 0; s < kStrips; ++s) h[s] = *reinterpret_cast<const v4f *>(heads + s);
+  int best = 0;
+  float bm = h[0].x;
+#pragma unroll
+  for (int s = 1; s < kStrips; ++s) { // strips ascend in lag: strict > keeps the first maximum
+    const float v = h[s].x;
+    if (v > bm) {
+      bm = v;
+      best = s;
+    }
+  }
+  // the peak strip's row, 64 values in registers (sixteen 16-byte loads in flight together)
+  float r[kRowLags];
+  {
+    const v4f *rp = reinterpret_cast<const v4f *>(rows + best * kRowLags);
+#pragma unroll
+    for (int q = 0; q < kRowLags / 4; ++q) {
+      const v4f t = rp[q];
+      r[4 * q] = t.x; r[4 * q + 1] = t.y; r[4 * q + 2] = t.z; r[4 * q + 3] = t.w;
+    }
+  }
+  const StripHead hb = heads[best];
+  const int p1 = hb.p1f & ~kHeadNoMax;
+  WindowResult w;
+  w.exact = !(hb.p1f & kHeadNoMax);
+  w.peak_value = bm;
+  w.peak_pos = (bm > -FLT_MAX) ? p1 : 0; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
+  // main-lobe walk (oracle/lte_oracle.c:300-308): right while avg[u+1] <= avg[u] and u < 9727, left while avg[l-1] <= avg[l]
+  // and l > 1; no left walk for a peak at lag <= 2.  Row index 32 is the peak; offsets beyond +-30 / 31: not closed here.
+  uint32_t mr = 0u, ml = 0u;
+#pragma unroll
+  for (int j = 1; j <= 30; ++j)
+    if (!(r[32 + j + 1] <= r[32 + j]) || p1 + j >= kConvLen - 1) mr |= 1u << j;
+#pragma unroll
+  for (int j = 1; j <= 31; ++j)
+    if (!(r[32 - j - 1] <= r[32 - j]) || p1 - j <= 1) ml |= 1u << j;
+  int j_r = 1, j_l = 1;
+  if (mr) j_r = __builtin_ctz(mr);
+  else w.exact = false;
+  if (p1 <= 2) j_l = p1; // pl_lb = 0
+  else if (ml) j_l = __builtin_ctz(ml);
+  else w.exact = false;
+  const int lb = p1 - j_l, ub = p1 + j_r;
+  // the largest value outside [lb, ub): the peak strip's own share ...
+  float out = hb.far;
+#pragma unroll
+  for (int i = 0; i < kRowLags; ++i) {
+    const int lag = p1 - 32 + i;
+    const bool counts = lag_owned(best, lag) && (lag < lb || lag >= ub);
+    const float x = counts ? r[i] : -FLT_MAX;
+    out = x > out ? x : out;
+  }
+  // ... and the other strips': their maximum, unless it lies on the slope of this lobe
+#pragma unroll
+  for (int s = 0; s < kStrips; ++s) {
+    if (s == best) continue;
+    const int p = __float_as_int(h[s].y) & ~kHeadNoMax;
+    float v = h[s].x;
+    if (p >= lb && p < ub) v = strip_outside_lobe(heads, rows, s, lb, ub);
+    if (v > out) out = v;
+  }
+  // empty ranges stand for their first element: the left one is empty exactly when the peak sits at lag <= 2,
+  // the right one when the lobe reaches lag 9726 (avg[9726..9727] = 0)
+  float sl = out;
+  if (w.peak_pos <= 2) sl = heads[0].a0;
   const float sr = (ub >= kNLags) ? 0.f : out;
   const float side = sl > sr ? sl : sr;
   w.psr = w.peak_value / side;

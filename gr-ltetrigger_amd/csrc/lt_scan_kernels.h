@@ -113,7 +113,8 @@ struct ScanArgs {
   const int *n_jobs;   // [2]: how many of each
   int jobs_cap;
   ChainState *state;   // [n_channels * 3]
-  StripPartial *parts; // [n_channels * 3][kScanMaxRound][12]
+  StripHead *heads;    // [n_channels * 3][kScanMaxRound][12]: what a strip says about a window (lt_scan.h, the deferred form) ...
+  float *rows;         // [n_channels * 3][kScanMaxRound][12][64]: ... and the 64 lags around its maximum
   const DeviceTables *tab;
   unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
   const float *cache;       // window cache (slots of kStrips x 64 * kStripRegs floats), or null
@@ -302,7 +303,8 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
     } else {
       strip_ema_load(st->avg[sel], strip, lane, ema);
     }
-    StripPartial *parts = a.parts + (int64_t)chain * kScanMaxRound * kStrips + strip;
+    StripHead *heads = a.heads + (int64_t)chain * kScanMaxRound * kStrips + strip;
+    float *rows = a.rows + ((int64_t)chain * kScanMaxRound * kStrips + strip) * kRowLags;
     const float *m = a.cache + (size_t)uniform_i32(jp->slot_base[root]) * (kStrips * 64 * kStripRegs) + (size_t)strip * (64 * kStripRegs) + lane;
     float met[kStripRegs], nxt[kStripRegs];
 #pragma unroll
@@ -326,9 +328,12 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       if (k < sq.n_a) {
         if (k == sq.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
       } else {
-        StripPartial p;
-        strip_resolve(ema, strip, ln, p);
-        if (lane == 0) parts[(int64_t)(k - sq.n_a) * kStrips] = p;
+        StripHead hd;
+        float row;
+        int idx;
+        strip_head_row(ema, strip, ln, hd, row, idx);
+        rows[(int64_t)(k - sq.n_a) * (kStrips * kRowLags) + idx] = row;
+        if (lane == 0) heads[(int64_t)(k - sq.n_a) * kStrips] = hd;
       }
     }
     strip_ema_store(st->avg[(sel + 2) % 3], strip, lane, ema);
@@ -357,7 +362,8 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       const cf32 hh = a.tab->pss_spec[root][lane + 64 * R];
       spec[R] = v2f{hh.re, hh.im};
     }
-    StripPartial *parts = a.parts + (int64_t)chain * kScanMaxRound * kStrips + strip;
+    StripHead *heads = a.heads + (int64_t)chain * kScanMaxRound * kStrips + strip;
+    float *rows = a.rows + ((int64_t)chain * kScanMaxRound * kStrips + strip) * kRowLags;
 #ifdef LT_SCAN_PROF
     unsigned tp = (unsigned)__builtin_amdgcn_s_memtime();
 #define LT_PSTAMP(i) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&PROF[w][i], t_ - tp); tp = t_; }
@@ -418,9 +424,14 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
         // average is a state the chain can be restarted from
         if (k == sq.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
       } else {
-        StripPartial p;
-        strip_resolve(ema, strip, ln, p);
-        if (lane == 0) parts[(int64_t)(k - sq.n_a) * kStrips] = p;
+        // (the deferred form: the strip's maximum, the 64 lags around it, the maximum over the rest -- the lobe is walked by
+        // the resolver, for the one strip of twelve that holds the window's peak)
+        StripHead hd;
+        float row;
+        int idx;
+        strip_head_row(ema, strip, ln, hd, row, idx);
+        rows[(int64_t)(k - sq.n_a) * (kStrips * kRowLags) + idx] = row;
+        if (lane == 0) heads[(int64_t)(k - sq.n_a) * kStrips] = hd;
       }
       LT_PSTAMP(7) // resolve + store
     }
@@ -699,7 +710,8 @@ __global__ __launch_bounds__(256) void lt_plan_kernel(PlanArgs a)
 struct ResolveArgs {
   ChainState *state;
   const ScanJob *jobs;
-  const StripPartial *parts;
+  const StripHead *heads; // (ScanArgs)
+  const float *rows;
   lt_record *recs;
   int rec_cap;
   int *rec_count;
@@ -777,7 +789,10 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
     const int nb = n_bc - blk < 64 ? n_bc - blk : 64;
     WindowResult wr;
     wr.peak_pos = 0; wr.peak_value = 0.f; wr.psr = 0.f; wr.exact = true;
-    if (lane < nb) wr = resolve_window_global(a.parts + ((int64_t)chain * kScanMaxRound + blk + lane) * kStrips);
+    if (lane < nb) {
+      const int64_t wi = ((int64_t)chain * kScanMaxRound + blk + lane) * kStrips;
+      wr = resolve_window_deferred(a.heads + wi, a.rows + wi * kRowLags);
+    }
     // ---- an idle chain (lib/pss_impl.cc:134-135: a miss with score 0 changes nothing but d_psr, the ring and the
     // position): all the misses up to the first window that fires, one lane each
     int k0 = 0;

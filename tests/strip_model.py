@@ -160,3 +160,88 @@ def combine(parts):
 
 def find_strips(avg):
     return combine([strip_partial(avg, s) for s in range(STRIPS)])
+
+
+# ---------------------------------------------------------------- the deferred form (scan rounds since round 5)
+# A root wave stops after the strip's maximum: it leaves a head (m1, p1, far = the maximum over its owned lags outside
+# the 64 lags around p1, a0) and the row of those 64 lags; the resolver walks the lobe of the one strip that holds the
+# window's peak (strip_head_row / resolve_window_deferred in csrc/lt_scan.h).
+def strip_head_row(avg, s):
+    e, lag = strip_regs(avg, s)
+    c0 = PITCH * s - HALO
+    off = np.arange(64)[None, :] + 64 * np.arange(REGS)[:, None]
+    own = (off >= HALO) & (off < HALO + PITCH) & (lag < NLAGS)
+    masked = np.where(own, e, -FLT_MAX)
+    m1 = masked.max()
+    r_p = l_p = -1
+    for r in range(REGS):
+        hit = np.nonzero(masked[r] == m1)[0]
+        if hit.size:
+            r_p, l_p = r, int(hit[0])
+            break
+    p1 = c0 + l_p + 64 * r_p
+    # per lane: maximum over its owned lags, and its second largest (with multiplicity: a tie gives m2 == m)
+    srt = np.sort(masked, axis=0)
+    m, m2 = srt[-1], srt[-2]
+    r_b = (r_p - 1 if r_p > 0 else 1) if l_p < 32 else (r_p + 1 if r_p < REGS - 1 else REGS - 2)
+    L = np.arange(64)
+    d = L - l_p
+    offs = ((d + 32) % 64) - 32
+    use_b = d != offs
+    row = np.where(use_b, e[r_b], e[r_p])
+    row_own = np.where(use_b, masked[r_b], masked[r_p])  # -FLT_MAX where the lag is not the strip's own
+    far_lane = np.where(row_own == m, m2, m)
+    out_row = np.zeros(64, np.float32)
+    out_row[offs + 32] = row
+    a0 = np.float32(e[0][HALO]) if s == 0 else np.float32(0)
+    return dict(m1=np.float32(m1), p1=int(p1), far=np.float32(far_lane.max()), a0=a0, row=out_row, s=s)
+
+
+def _owned(s, lag):
+    return PITCH * s <= lag < PITCH * (s + 1) and lag < NLAGS
+
+
+def _outside(h, lb, ub):
+    v = h["far"]
+    for i in range(64):
+        lag = h["p1"] - 32 + i
+        if _owned(h["s"], lag) and (lag < lb or lag >= ub) and h["row"][i] > v:
+            v = h["row"][i]
+    return v
+
+
+def combine_deferred(heads):
+    best = 0
+    for s in range(1, STRIPS):
+        if heads[s]["m1"] > heads[best]["m1"]:
+            best = s
+    hb = heads[best]
+    p1, r = hb["p1"], hb["row"]
+    peak_value = hb["m1"]
+    peak = p1 if peak_value > -FLT_MAX else 0
+    j_r = next((j for j in range(1, 31) if (not r[32 + j + 1] <= r[32 + j]) or p1 + j >= CONV_LEN - 1), None)
+    if p1 <= 2:
+        j_l = p1
+    else:
+        j_l = next((j for j in range(1, 32) if (not r[32 - j - 1] <= r[32 - j]) or p1 - j <= 1), None)
+    if j_r is None or j_l is None:
+        return None
+    lb, ub = p1 - j_l, p1 + j_r
+    out = _outside(hb, lb, ub)
+    for s in range(STRIPS):
+        if s == best:
+            continue
+        q = heads[s]
+        v = _outside(q, lb, ub) if lb <= q["p1"] < ub else q["m1"]
+        if v > out:
+            out = v
+    sl = heads[0]["a0"] if peak <= 2 else out
+    sr = np.float32(0) if ub >= NLAGS else out
+    side = sl if sl > sr else sr
+    with np.errstate(divide="ignore", invalid="ignore"):
+        psr = np.float32(peak_value) / np.float32(side)
+    return peak, np.float32(peak_value), psr
+
+
+def find_strips_deferred(avg):
+    return combine_deferred([strip_head_row(avg, s) for s in range(STRIPS)])

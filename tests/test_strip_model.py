@@ -21,14 +21,19 @@ def _vec(rng, kind):
 
 
 def _check(a):
+    """Both decompositions -- the strips' own lobe walks (per-chain kernels) and the deferred form (scan rounds: heads and
+    rows, the resolver walks the one lobe that matters) -- against the direct algorithm."""
     want = M.find_reference(a)
-    got = M.find_strips(a)
-    if got is None:
-        return False
-    assert got[0] == want[0], (got, want)
-    assert got[1] == want[1]
-    assert (got[2] == want[2]) or (np.isnan(got[2]) and np.isnan(want[2])), (got, want)
-    return True
+    ok = True
+    for find in (M.find_strips, M.find_strips_deferred):
+        got = find(a)
+        if got is None:
+            ok = False
+            continue
+        assert got[0] == want[0], (find.__name__, got, want)
+        assert got[1] == want[1]
+        assert (got[2] == want[2]) or (np.isnan(got[2]) and np.isnan(want[2])), (find.__name__, got, want)
+    return ok
 
 
 @pytest.mark.parametrize("kind", ["exp", "smooth", "gamma"])
@@ -79,12 +84,14 @@ def test_wide_lobe_is_flagged_not_wrong():
     for d in range(-60, 61):
         a[p + d] = 50.0 - 0.5 * abs(d)
     assert M.find_strips(a) is None
+    assert M.find_strips_deferred(a) is None
 
 
 def test_degenerate_vectors_do_not_crash():
     for a in (np.zeros(M.CONV_LEN + 1, np.float32), np.ones(M.CONV_LEN + 1, np.float32)):
         a[M.NLAGS:] = 0
-        got = M.find_strips(a)
-        if got is not None:
-            want = M.find_reference(a)
-            assert got[0] == want[0]
+        for find in (M.find_strips, M.find_strips_deferred):
+            got = find(a)
+            if got is not None:
+                want = M.find_reference(a)
+                assert got[0] == want[0]

@@ -85,11 +85,16 @@ int main(int argc, char **argv)
     memset(hst.data(), 0, sizeof(ChainState) * hst.size());
     CK(hipMemcpy(dst, hst.data(), sizeof(ChainState) * hst.size(), hipMemcpyHostToDevice));
   }
-  StripPartial *dparts;
-  CK(hipMalloc(&dparts, sizeof(StripPartial) * (size_t)n_ch * 3 * kScanMaxRound * kStrips));
+  const size_t n_parts = (size_t)n_ch * 3 * kScanMaxRound * kStrips;
+  StripHead *dheads;
+  float *drows;
+  CK(hipMalloc(&dheads, sizeof(StripHead) * n_parts));
+  CK(hipMalloc(&drows, sizeof(float) * kRowLags * n_parts));
+  CK(hipMemset(dheads, 0, sizeof(StripHead) * n_parts));
+  CK(hipMemset(drows, 0, sizeof(float) * kRowLags * n_parts));
   ScanArgs a;
   a.iq = diq; a.ch_stride = n; a.hist = nullptr; a.hist_stride = 0; a.t0 = 0; a.n = n; a.hist_len = 0;
-  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.parts = dparts; a.tab = dtab; a.jobs_cap = n_ch;
+  a.jobs = djobs; a.n_jobs = dnj; a.state = dst; a.heads = dheads; a.rows = drows; a.tab = dtab; a.jobs_cap = n_ch;
   unsigned long long *dprof;
   CK(hipMalloc(&dprof, 8 * 128));
   CK(hipMemset(dprof, 0, 8 * 128));
@@ -140,24 +145,34 @@ int main(int argc, char **argv)
   }
 #endif
   {
-    std::vector<StripPartial> all((size_t)n_ch * 3 * kScanMaxRound * kStrips);
-    CK(hipMemcpy(all.data(), dparts, sizeof(StripPartial) * all.size(), hipMemcpyDeviceToHost));
-    unsigned long long sum = 0;
+    // checksum of what the strips leave for the resolver (heads and rows), and of the resolver's results on them (computed on
+    // the host with the kernel's own arithmetic order: peak position and the bits of the side-lobe maximum)
+    std::vector<StripHead> heads(n_parts);
+    std::vector<float> rows(n_parts * kRowLags);
+    CK(hipMemcpy(heads.data(), dheads, sizeof(StripHead) * n_parts, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(rows.data(), drows, sizeof(float) * rows.size(), hipMemcpyDeviceToHost));
+    unsigned long long sum = 0, rsum = 0;
     for (int c = 0; c < n_ch * 3; ++c)
       if ((roots >> (c % 3)) & 1)
         for (int k = 0; k < n_win; ++k)
           for (int st = 0; st < kStrips; ++st) {
-            const StripPartial &q = all[((size_t)c * kScanMaxRound + k) * kStrips + st];
-            unsigned m, sv;
+            const size_t i = ((size_t)c * kScanMaxRound + k) * kStrips + st;
+            const StripHead &q = heads[i];
+            unsigned m, f, a0;
             memcpy(&m, &q.m1, 4);
-            memcpy(&sv, &q.s, 4);
-            sum = sum * 1000003ull + m + 3ull * sv + 7ull * (unsigned)q.p1 + 11ull * (unsigned)q.lb + 13ull * (unsigned)q.ub + q.flags;
+            memcpy(&f, &q.far, 4);
+            memcpy(&a0, &q.a0, 4);
+            sum = sum * 1000003ull + m + 3ull * f + 7ull * (unsigned)q.p1f + 5ull * a0;
+            for (int j = 0; j < kRowLags; ++j) {
+              unsigned v;
+              memcpy(&v, &rows[i * kRowLags + j], 4);
+              rsum = rsum * 1000003ull + v;
+            }
           }
-    printf("checksum of the partials (roots %d, %d sequences): %016llx\n", roots, n_seq, sum);
+    printf("checksum of the heads (roots %d, %d sequences): %016llx   of the rows: %016llx\n", roots, n_seq, sum, rsum);
+    for (int i = 0; i < 24; ++i)
+      printf("head[%d]: m1=%g p1=%d far=%g a0=%g  row[30..34]=%g %g %g %g %g\n", i, heads[i].m1, heads[i].p1f, heads[i].far, heads[i].a0, rows[(size_t)i * kRowLags + 30],
+             rows[(size_t)i * kRowLags + 31], rows[(size_t)i * kRowLags + 32], rows[(size_t)i * kRowLags + 33], rows[(size_t)i * kRowLags + 34]);
   }
-  std::vector<StripPartial> hp((size_t)kStrips * 4);
-  CK(hipMemcpy(hp.data(), dparts, sizeof(StripPartial) * hp.size(), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 24; ++i)
-    printf("part[%d]: m1=%g p1=%d s=%g lb=%d ub=%d a0=%g flags=%u\n", i, hp[i].m1, hp[i].p1, hp[i].s, hp[i].lb, hp[i].ub, hp[i].a0, hp[i].flags);
   return 0;
 }
