@@ -168,6 +168,7 @@ def parse_args(argv=None):
                     help="skip `match_vs_oracle` (every rank: the CPU oracle on its own channels, outside the timed region)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-config2", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the streaming leg (lt_batch_push in 10 ms / 100 ms chunks)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (SNR sweep at 30.72 Msps)")
     ap.add_argument("--config5-trials", type=int, default=50, help="seeded trials per SNR point of the config5 leg")
     ap.add_argument("--config5-snrs", default="", help="comma-separated SNRs in dB (default -10..10 in steps of 2)")
@@ -537,6 +538,12 @@ def main():
         # the side measurements run at N = 1 only (rank 0 would keep the other ranks waiting at the last barrier)
         if e2e is not None:
             out["end_to_end"] = e2e
+        if world == 1 and not args.no_streaming:
+            out["streaming"] = {
+                "what": "lt_batch_push: the same 64 channels as a stream, chunk by chunk from pinned host memory (H2D of the next "
+                        "chunk under this chunk's kernels, records back per chunk); wall time per chunk on one GPU",
+                "chunks_10ms": streaming(torch, lt, iq, n_ch, n, local_rank, 19200, recs),
+                "chunks_100ms": streaming(torch, lt, iq, n_ch, n, local_rank, 192000, recs)}
         if world == 1 and not args.no_config2:
             out["config2"] = config2(torch, lt, dev, local_rank)
         if world == 1 and not args.no_config5:
@@ -610,6 +617,78 @@ def end_to_end(torch, lt, iq, n_ch, n, device):
             "ms_per_pass": round(dt / passes * 1e3, 3),
             "h2d_gbs": round(n_ch * n * 8.0 * passes / dt / 1e9, 2),
             "what": "pinned host -> hipMemcpyAsync -> kernels -> records D2H, double-buffered over two streams; one GPU"}
+
+
+def streaming(torch, lt, iq, n_ch, n, device, chunk_samples, ref_recs, seconds=None):
+    """The reference is a streaming block (set_history(9600), consume_each: lib/pss_impl.cc:81-82,195): the same n_ch
+    channels fed as a STREAM, in chunks of chunk_samples per channel from pinned host memory -- per chunk: H2D into one of
+    two device buffers (on a copy stream, the next chunk's copy under this chunk's kernels), lt_batch_push on the device
+    buffer, the chunk's records back to the host (lt_batch_collect).  Wall time per chunk, as a factor over real time, and
+    the records of all chunks together against the single run's."""
+    from oracle import oracle as O
+    dev = iq.device
+    n_chunks = n // chunk_samples
+    if seconds is not None:
+        n_chunks = min(n_chunks, max(2, int(round(seconds * FS / chunk_samples))))
+    total = n_chunks * chunk_samples
+    # chunk-major pinned memory: what a capture front end hands over every chunk_samples / 1.92 MHz seconds
+    host = torch.empty((n_chunks, n_ch, chunk_samples), dtype=torch.complex64, pin_memory=True)
+    host.copy_(iq[:, :total].reshape(n_ch, n_chunks, chunk_samples).permute(1, 0, 2))
+    torch.cuda.synchronize()
+    dbuf = [torch.empty((n_ch, chunk_samples), dtype=torch.complex64, device=dev) for _ in range(2)]
+    b = lt.Batch(n_ch, chunk_samples, psr_threshold=4.0, device=device)
+    b.set_phase_timing(0)
+    s_run, s_copy = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    copied = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def feed(k):  # H2D of chunk k into buffer k & 1, once the push that read that buffer two chunks ago is through
+        with torch.cuda.stream(s_copy):
+            if k >= 2:
+                s_copy.wait_event(freed[k & 1])
+            dbuf[k & 1].copy_(host[k], non_blocking=True)
+            copied[k & 1].record(s_copy)
+
+    def one_pass(timed):
+        b.reset()
+        got = [[] for _ in range(3 * n_ch)]
+        per_chunk = []
+        feed(0)
+        t_start = time.perf_counter()
+        for k in range(n_chunks):
+            t0 = time.perf_counter()
+            if k + 1 < n_chunks:
+                feed(k + 1)
+            s_run.wait_event(copied[k & 1])
+            b.push_device(torch.view_as_real(dbuf[k & 1]).data_ptr(), chunk_samples, end_of_stream=(k == n_chunks - 1), stream=s_run.cuda_stream)
+            freed[k & 1].record(s_run)
+            recs = b.collect()  # (synchronises the run's stream: the chunk's records are on the host when it returns)
+            per_chunk.append(time.perf_counter() - t0)
+            if not timed:
+                for c, r in enumerate(recs):
+                    if len(r):
+                        got[c].append(r.copy())
+        return time.perf_counter() - t_start, per_chunk, got
+    _, _, got = one_pass(False)  # warm-up, and the records that are compared
+    dt, per_chunk, _ = one_pass(True)
+    launches = b.last_launch_count()
+    b.close()
+    # the records of the stream = those of the single run up to where the stream ends (same parity bar as every comparison;
+    # the stream's last call may be missing where the shorter capture ends inside it)
+    ok = True
+    if total == n:
+        for c in range(3 * n_ch):
+            g = np.concatenate(got[c]) if got[c] else np.zeros(0, lt.RECORD_DTYPE)
+            w = ref_recs[c]
+            m = min(len(g), len(w))
+            ok = ok and len(g) == len(w) and O.first_difference(g[:m], w[:m]) is None
+    pc = np.array(per_chunk) * 1e6
+    chunk_s = chunk_samples / FS
+    return {"chunk_ms": round(chunk_s * 1e3, 3), "chunks": n_chunks, "us_per_chunk": round(dt / n_chunks * 1e6, 1),
+            "us_per_chunk_p50": round(float(np.median(pc)), 1), "us_per_chunk_max": round(float(pc.max()), 1),
+            "realtime_factor": round(chunk_s / (dt / n_chunks), 1), "value": round(n_ch * total / dt / 1e6, 1), "unit": "Msamp/s",
+            "h2d_gbs": round(n_ch * total * 8.0 / dt / 1e9, 2), "launches_per_chunk": launches,
+            "records_match_single_run": bool(ok) if total == n else None}
 
 
 def config2(torch, lt, dev, device):

@@ -44,7 +44,7 @@ EXPORTS = [
     "lt_sss_N_id_1", "lt_sync_get_cell_id",
     "lt_batch_create", "lt_batch_free", "lt_batch_reset", "lt_batch_set_mode", "lt_batch_set_psr_threshold",
     "lt_batch_run", "lt_batch_collect", "lt_batch_collect_previous", "lt_batch_record_capacity", "lt_batch_enable_halfframes",
-    "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_phase_ms", "lt_batch_push",
+    "lt_batch_get_halfframes", "lt_batch_last_kernel_ms", "lt_batch_last_launch_count", "lt_batch_phase_ms", "lt_batch_push",
     "lt_batch_get_mode", "lt_batch_set_scan_segments", "lt_batch_set_overlap", "lt_batch_debug_hold_records", "lt_batch_set_phase_timing", "lt_batch_set_window_cache", "lt_batch_cache_stats", "lt_batch_set_scan_groups",
     "lt_decim_create", "lt_decim_free", "lt_decim_ntaps", "lt_decim_get_taps", "lt_decim_run",
 ]
@@ -137,6 +137,7 @@ def lib():
     L.lt_batch_enable_halfframes.argtypes = [vp, i64]
     L.lt_batch_get_halfframes.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.lt_batch_last_kernel_ms.argtypes = [vp, C.POINTER(f32)]
+    L.lt_batch_last_launch_count.argtypes = [vp, C.POINTER(i32)]
     L.lt_batch_phase_ms.argtypes = [vp, i32, C.POINTER(f32)]
     L.lt_decim_create.argtypes = [pp, i32, i32]
     L.lt_decim_free.argtypes = [vp]
@@ -432,6 +433,12 @@ class Batch:
         ms = (C.c_float * 4)()
         _check(lib().lt_batch_phase_ms(self._h, int(runs_back), ms), "lt_batch_phase_ms")
         return tuple(float(v) for v in ms)
+
+    def last_launch_count(self):
+        """Kernel launches the last run enqueued (lt_batch_last_launch_count)."""
+        n = C.c_int()
+        _check(lib().lt_batch_last_launch_count(self._h, C.byref(n)), "lt_batch_last_launch_count")
+        return n.value
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -178,6 +178,7 @@ struct lt_batch {
   int phase_timing = 2;            // lt_batch_set_phase_timing: 2 = events between the stages of a run, 1 = around it, 0 = none
   bool ev_phased[kPhaseRing] = {}; // the run in this slot recorded the stage events
   bool ev_timed = false;           // the last run recorded its first and last event
+  int last_launches = 0;           // kernel launches the last run enqueued (lt_batch_last_launch_count)
   bool ran = false;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
@@ -792,6 +793,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.records_delay_us = b->records_delay_us;
   R.wait_hint = b->d_wait_hint;
   R.run_id = (int)((b->n_runs + 1) & 0x3fffffff);
+  R.n_launches = &b->last_launches;
   // h_wait_hint[0] = the last run in which a chain asked, [1] = the last run whose per-chain kernel is known to have run:
   // everything up to run [1] - 1 is through (stream order), so "nobody asked in the latest run known in full" is
   // [0] <= [1] - 2.  The host may be any number of runs ahead of the device; until it knows of a run, two passes.
@@ -872,6 +874,14 @@ int lt_batch_phase_ms(lt_batch *b, int runs_back, float ms[4])
   HIP_TRY(hipEventElapsedTime(&ms[0], e[0], e[1]));
   HIP_TRY(hipEventElapsedTime(&ms[2], e[1], e[2]));
   HIP_TRY(hipEventElapsedTime(&ms[3], e[2], e[3]));
+  return LT_OK;
+}
+
+int lt_batch_last_launch_count(lt_batch *b, int *n_launches)
+{
+  if (!b || !n_launches) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
+  if (!b->ran) return fail(LT_ERROR, "no run yet");
+  *n_launches = b->last_launches;
   return LT_OK;
 }
 

@@ -585,6 +585,8 @@ static int2 *work_list(const RunLaunch &R, int n_chains)
 
 hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t records_stream)
 {
+  int n_launch = 0; // kernel launches of this run (lt_batch_last_launch_count)
+#define LT_LAUNCH(...) do { ++n_launch; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
   const int n_chains = R.n_channels * 3;
   if (R.rec_cap <= 0 || n_chains <= 0) return hipErrorInvalidValue;
   if ((R.rec_cap + 3) / 4 > 65535) return hipErrorInvalidValue; // (a chunk of > 37 minutes)
@@ -679,7 +681,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     mm.hist_len = R.hist_len; mm.slot_owner = p.slot_owner; mm.slot_pos = p.slot_pos; mm.launch_slots = R.n_jobs + kCtrLaunchSlots;
     mm.slot_cap = R.slot_cap; mm.quota = 0; mm.cache = reinterpret_cast<float *>(R.cache); mm.tab = R.tab;
     const int metric_grid = 4 * (R.n_cus > 0 ? R.n_cus : 256);
-    hipLaunchKernelGGL(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
+    LT_LAUNCH(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
       s.jobs = q.jobs = jobs2[r & 1];
       s.n_jobs = R.n_jobs + 2 * r;
@@ -693,12 +695,12 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       if (cached_scan) { // the lag metrics of this round's windows, before its scan (the round's slots: from 0)
         mm.n_before = 0;
         mm.launch_slots = R.n_jobs + kCtrLaunchSlots + r;
-        hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)metric_grid), dim3(64 * kMetricWaves), 0, stream, mm);
+        LT_LAUNCH(lt_metric_kernel, dim3((unsigned)metric_grid), dim3(64 * kMetricWaves), 0, stream, mm);
       }
-      if (G == 1) hipLaunchKernelGGL(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
-      else if (G == 2) hipLaunchKernelGGL(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
-      else hipLaunchKernelGGL(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
-      hipLaunchKernelGGL(lt_resolve_kernel, dim3(R.n_channels), dim3(192), 0, stream, q);
+      if (G == 1) LT_LAUNCH(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
+      else if (G == 2) LT_LAUNCH(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
+      else LT_LAUNCH(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
+      LT_LAUNCH(lt_resolve_kernel, dim3(R.n_channels), dim3(192), 0, stream, q);
       if (debug_jobs) { // diagnostics: the jobs of this round
         (void)hipStreamSynchronize(stream);
         int njj[2] = {0, 0};
@@ -770,7 +772,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.run_id = R.run_id;
     if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && c.slot_quota >= kCacheMinSearches && R.cache_level >= 1 && R.two_pass)) c.cache = nullptr;
     c.stream = R.stream && c.cache;
-    hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+    LT_LAUNCH(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     if (c.cache) {
       // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
       MetricArgs m;
@@ -779,11 +781,11 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       m.n_before = 0; m.slot_cap = c.slot_cap; m.quota = c.slot_quota;
       m.cache = c.cache; m.tab = R.tab;
       const int n_cus = R.n_cus > 0 ? R.n_cus : 256;
-      hipLaunchKernelGGL(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);
+      LT_LAUNCH(lt_metric_kernel, dim3((unsigned)(4 * n_cus)), dim3(64 * kMetricWaves), 0, stream, m);
       c.pass = 1;
       // (level 4: the chains with a stream first, in the kernel that has nothing but the stream to search in)
-      if (c.stream) hipLaunchKernelGGL(lt_chain_stream_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
-      hipLaunchKernelGGL(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+      if (c.stream) LT_LAUNCH(lt_chain_stream_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+      LT_LAUNCH(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
     }
   }
   if (R.ev_chain_done) (void)hipEventRecord(R.ev_chain_done, stream);
@@ -803,15 +805,15 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.scratch = reinterpret_cast<RecordScratch *>(R.cp_scratch); c.state = state; c.tab = R.tab; c.n_chains = n_chains;
     c.list = work_list(R, n_chains);
     c.list_count = R.n_jobs + kCtrList + (R.list_slot ? 1 : 0);
-    if (R.records_delay_us > 0) hipLaunchKernelGGL(lt_delay_kernel, dim3(1), dim3(64), 0, rs, (long long)R.records_delay_us * 100);
-    hipLaunchKernelGGL(lt_cpsss_kernel, dim3((unsigned)kListBlocks), dim3(256), 0, rs, c);
-    hipLaunchKernelGGL(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
+    if (R.records_delay_us > 0) LT_LAUNCH(lt_delay_kernel, dim3(1), dim3(64), 0, rs, (long long)R.records_delay_us * 100);
+    LT_LAUNCH(lt_cpsss_kernel, dim3((unsigned)kListBlocks), dim3(256), 0, rs, c);
+    LT_LAUNCH(lt_cp_scan_kernel, dim3((unsigned)n_chains), dim3(64), 0, rs, c);
     if (R.out_hf && R.out_cap > 0) {
       HfArgs h;
       h.iq = iq; h.ch_stride = R.ch_stride; h.hist = hist; h.hist_stride = R.hist_stride; h.t0 = R.t0; h.n = R.n;
       h.hist_len = R.hist_len; h.recs = R.recs; h.rec_cap = R.rec_cap; h.rec_count = R.rec_count;
       h.out_hf = reinterpret_cast<v2f *>(R.out_hf); h.out_cap = R.out_cap; h.tab = R.tab;
-      hipLaunchKernelGGL(lt_hf_kernel, dim3((unsigned)n_chains, (unsigned)R.rec_cap), dim3(256), 0, rs, h);
+      LT_LAUNCH(lt_hf_kernel, dim3((unsigned)n_chains, (unsigned)R.rec_cap), dim3(256), 0, rs, h);
     }
   }
   // ---- history for the next chunk
@@ -819,8 +821,10 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     HistArgs h;
     h.iq = iq; h.ch_stride = R.ch_stride; h.hist_old = hist; h.hist_new = reinterpret_cast<v2f *>(R.hist_new);
     h.hist_stride = R.hist_stride; h.n = R.n; h.hist_len_old = R.hist_len; h.hist_len_new = R.hist_len_new;
-    hipLaunchKernelGGL(lt_hist_kernel, dim3((unsigned)((R.hist_len_new + 255) / 256), (unsigned)R.n_channels), dim3(256), 0, stream, h);
+    LT_LAUNCH(lt_hist_kernel, dim3((unsigned)((R.hist_len_new + 255) / 256), (unsigned)R.n_channels), dim3(256), 0, stream, h);
   }
+#undef LT_LAUNCH
+  if (R.n_launches) *R.n_launches = n_launch;
   return hipGetLastError();
 }
 

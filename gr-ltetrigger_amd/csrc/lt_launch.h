@@ -62,6 +62,7 @@ struct RunLaunch {
   int stream = 0;             // window cache level 4: untracked chains ask for their lag-metric stream (lt_chain_kernel.h)
   int two_pass = 1;           // 0: the per-chain kernel in one pass without the cache (no lt_metric_kernel, no second launch):
                               // no chain asked in the latest run the caller knows in full.  Timing only, never a record
+  int *n_launches = nullptr;  // host: out, the number of kernel launches the run enqueued
   int list_slot = 0;          // which of the two work lists (and of their counters behind the job counters) this run uses (0 / 1)
 };
 

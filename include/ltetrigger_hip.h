@@ -275,6 +275,9 @@ int lt_batch_enable_halfframes(lt_batch *b, int64_t max_per_chain);
 int lt_batch_get_halfframes(lt_batch *b, int chain, lt_cf32 *out, int64_t cap, int64_t *count);
 /* Device time of the chain kernel of the last run, in milliseconds (HIP events on the run's stream). */
 int lt_batch_last_kernel_ms(lt_batch *b, float *ms);
+/* Kernel launches the last lt_batch_run / lt_batch_push enqueued (state reset and copies not counted): what a chunk of a
+ * stream costs beside its bytes.  No reference counterpart (diagnostics). */
+int lt_batch_last_launch_count(lt_batch *b, int *n_launches);
 /* The same, per stage, of the run `runs_back` runs ago (0 = the last one; the last 8 are kept):
  * ms[0] = plan + grid scan + resolve (all segments), ms[1] = 0, ms[2] = per-chain kernel, ms[3] = the
  * per-record kernels (CP length, SSS) and the history copy. */

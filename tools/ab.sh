@@ -20,7 +20,7 @@ for v in $LIBS; do
   for level in ${LEVELS:-4}; do for snr in ${SNRS:-20}; do
     rm -rf gpurun_out/pp
     LTETRIGGER_HIP_LIB=$f rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pp -- python3 bench.py --snr-db "$snr" --window-cache "$level" \
-      --steps "${STEPS:-6}" --warmup "${WARMUP:-3}" --no-end-to-end --no-config2 --no-config5 --no-cpu-baseline --no-overlap-leg --no-steady-leg --no-oracle-check \
+      --steps "${STEPS:-6}" --warmup "${WARMUP:-3}" --no-end-to-end --no-config2 --no-config5 --no-cpu-baseline --no-overlap-leg --no-steady-leg --no-oracle-check --no-streaming \
       > "gpurun_out/ab_${v}_${level}_${snr}.json" 2> gpurun_out/ab_stderr.txt || { tail -20 gpurun_out/ab_stderr.txt >&2; exit 1; }
     echo "$v ($sha) level $level SNR $snr: $(python tools/timeline.py gpurun_out/pp | tail -1)"
   done; done
