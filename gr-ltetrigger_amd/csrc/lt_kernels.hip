@@ -110,9 +110,9 @@ __global__ __launch_bounds__(128) void lt_sss_m0m1_kernel(const v2f *__restrict_
 // owns B = 32 / D ADJACENT outputs, so that one sample read serves B taps -- sample i is tap j of output k and tap j + D of
 // output k + 1 --: per step s one 8-byte LDS read and B packed FMAs, acc[b] += taps[s + b D] * X_s, where X_s is
 // the sample D B l + const - s for lane l.  Every accumulator sees its taps in ascending order.  The block's input span is
-// staged in LDS phase by phase, 32 phases (sample u at row u mod 32, column u / 32): for a given step all lanes of a
-// wave read one row at consecutive columns (conflict-free 8-byte reads), and the staging stores of a 16-lane group go to
-// 16 rows that start on distinct even banks (row length 273 = 1 mod 16).  32 phases x 256 threads x 8 B = 70 KB: two
+// staged in LDS in pairs of samples, 16 rows (decim_row2 below: sample u in entry (u + 1) / 2, entry v at row v mod 16,
+// column v / 16): for a given pair of steps all lanes of a wave read one row at consecutive columns (conflict-free 16-byte
+// reads).  16 rows x 275 entries x 16 B = 70 KB: two
 // blocks per CU, one staging its samples while the other computes.  The taps are wave-uniform: scalar loads, 32 at a time
 // from a table laid out in the order the steps use them (decim_tap_table).
 // Algorithmic bytes: 8 B in + 8/D B out per input sample; arithmetic: 2 NTAPS / D FMAs per input sample.
@@ -134,6 +134,18 @@ __host__ __device__ constexpr int decim_row(int ntaps)
   return r;
 }
 
+// Samples in pairs (round 5): sample u sits in the 16-byte LDS entry v = (u + 1) >> 1, half (u + 1) & 1; entry v at row
+// v mod 16, column v / 16 (rows of R2 entries, R2 odd: the staging stores of a 16-lane group -- eight or nine entries in
+// consecutive rows -- fall on distinct banks).  Two consecutive steps n (even), n + 1 of a lane read the samples u, u - 1 =
+// both halves of ONE entry: one ds_read_b128 per two steps instead of two ds_read_b64 -- half the LDS instructions for the
+// same bytes.  Same sums in the same order: bit-exact, 2-4 % faster (profiles/r05_decim_probe.txt).
+__host__ __device__ constexpr int decim_row2(int ntaps) // row length in 16-byte entries: >= threads + lead / phases + 2, odd
+{
+  int r = kDecimThreads + decim_lead(ntaps) / kDecimPhases + 2;
+  while (r % 2 != 1) ++r;
+  return r;
+}
+
 __device__ __forceinline__ v2f fma_tap(float t, v2f x, v2f acc)
 {
   const v2f tt = {t, t};
@@ -151,7 +163,12 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
   static_assert(T + lead / P <= R, "row too short");
   constexpr int n_steps = kNtaps + (B - 1) * kD; // s = -(B - 1) D .. NTAPS - 1
   constexpr int W0 = lead + P - kD; // u = 32 tid + W0 - n for step n
-  __shared__ v2f xs[P * R];
+  static_assert(P == 32 && (lead % 2) == 0 && (kD % 2) == 0 && (T % 32) == 0, "the pair layout assumes 32 phases and an even alignment");
+  constexpr int R2 = decim_row2(kNtaps);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) v4f xs4[16 * R2];
+  v2f *xs = reinterpret_cast<v2f *>(xs4);
+  static_assert(((P * T + lead + 1) / 2) / 16 + 1 <= R2 && R <= 2 * R2, "row too short for the pairs");
   const int tid = threadIdx.x, c = blockIdx.y;
   const int64_t k0 = (int64_t)blockIdx.x * (T * B);
   const int64_t first = k0 * kD - lead; // input sample of u = 0
@@ -164,8 +181,10 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
     const v2f *bp = x + (int64_t)c * n_in + base_i;
     const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<v2f *>(bp), 0, (int)avail * (int)sizeof(v2f), 0x00020000);
     const int shift = (int)(first - base_i); // <= 0: offsets of samples in front of the stream wrap to huge unsigned values
-    const int row = tid & (P - 1), col0 = tid / P;
-    v2f *dst = xs + row * R + col0;
+    // sample u = tid + i T: entry v = ((tid + 1) >> 1) + i T / 2 -- row and half fixed per thread, 8 columns on per load
+    const int v0 = (tid + 1) >> 1;
+    v2f *dst = xs + 2 * ((v0 & 15) * R2 + (v0 >> 4)) + ((tid + 1) & 1);
+    constexpr int kDstStep = 2 * (T / 32);
     constexpr int n_it = (span + T - 1) / T;
     constexpr int kBatch = n_it; // all of a thread's loads in flight together: one memory round trip per block
 #pragma unroll
@@ -178,14 +197,14 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
       }
 #pragma unroll
       for (int i = 0; i < kBatch; ++i)
-        if (i0 + i < n_it && (tid + (i0 + i) * T < span)) dst[(i0 + i) * (T / P)] = v[i];
+        if (i0 + i < n_it && (tid + (i0 + i) * T < span)) dst[(i0 + i) * kDstStep] = v[i];
     }
   }
   __syncthreads();
   v2f acc[B];
 #pragma unroll
   for (int b = 0; b < B; ++b) acc[b] = v2f{0.f, 0.f};
-  const v2f *xl = xs + tid;
+  const v4f *xl4 = xs4 + tid;
   // Step n (= s + (B - 1) D) reads sample u = 32 tid + W0 - n: row (W0 - n) mod 32, column tid + (W0 - n) / 32; output b
   // takes it with tap j = n + (b - (B - 1)) D.  The steps run in units of U = D (32 taps each: two scalar loads of 16
   // from the table `tt`, laid out [unit][step][output] by decim_tap_table below); a unit's LDS reads and taps are fetched
@@ -194,15 +213,19 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
   static_assert(U * B == 32 && G % 2 == 0, "a unit is 32 taps; the two buffers alternate in step with the chunks");
   constexpr int m_last = (n_steps - 1) / P; // chunks 0 and m_last have (step, output) pairs without a tap: unrolled apart
   static_assert(m_last >= 2 && P * (m_last - 1) + P - 1 <= kNtaps - 1 && P * 1 - (B - 1) * kD >= 0, "the steady chunks must lie inside the taps");
-  v2f xv[2][U];
+  static_assert(U % 2 == 0 && (W0 % 2) == 0, "steps pair up inside a unit");
+  v4f xq[2][U / 2];
   float tv[2][32];
   // unit g of chunk m: steps n = 32 m + g U + u
+  // (steps n = 32 m + r and n + 1, r even: the samples 32 tid + e and 32 tid + e - 1, e = W0 - n even -- the two halves of
+  // entry 16 tid + e / 2: row (e / 2) mod 16, column tid + e / 32)
+#define LT_DECIM_X(g, u) (((u) & 1) ? v2f{xq[(g) & 1][(u) / 2].x, xq[(g) & 1][(u) / 2].y} : v2f{xq[(g) & 1][(u) / 2].z, xq[(g) & 1][(u) / 2].w})
 #define LT_DECIM_LOAD(m, g, kPeel)                                                                       \
   {                                                                                                      \
-    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                        \
+    _Pragma("unroll") for (int u = 0; u < U; u += 2)                                                     \
     {                                                                                                    \
       const int r = (g) * U + u;                                                                         \
-      if (!kPeel || P * (m) + r < n_steps) xv[(g) & 1][u] = xl[((W0 - r) & (P - 1)) * R + ((W0 - r) / P) - (m)]; \
+      if (!kPeel || P * (m) + r < n_steps) xq[(g) & 1][u / 2] = xl4[(((W0 - r) / 2) & 15) * R2 + ((W0 - r) / P) - (m)]; \
     }                                                                                                    \
     const float *tp = tt + ((m) * G + (g)) * 32;                                                         \
     _Pragma("unroll") for (int i = 0; i < 32; ++i) tv[(g) & 1][i] = tp[i];                               \
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
       _Pragma("unroll") for (int b = 0; b < B; ++b)                                                      \
       {                                                                                                  \
         const int j = n + (b - (B - 1)) * kD;                                                            \
-        if (!kPeel || (n < n_steps && j >= 0 && j < kNtaps)) acc[b] = fma_tap(tv[(g) & 1][u * B + b], xv[(g) & 1][u], acc[b]); \
+        if (!kPeel || (n < n_steps && j >= 0 && j < kNtaps)) acc[b] = fma_tap(tv[(g) & 1][u * B + b], LT_DECIM_X(g, u), acc[b]); \
       }                                                                                                  \
     }                                                                                                    \
   }
@@ -239,6 +262,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
 #undef LT_DECIM_CHUNK
 #undef LT_DECIM_FMA
 #undef LT_DECIM_LOAD
+#undef LT_DECIM_X
   const int64_t k = k0 + (int64_t)B * tid;
   v2f *yo = y + (int64_t)c * n_out + k;
   if (k + B <= n_out) {
