@@ -796,7 +796,8 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.n_launches = &b->last_launches;
   // h_wait_hint[0] = the last run in which a chain asked, [1] = the last run whose per-chain kernel is known to have run:
   // everything up to run [1] - 1 is through (stream order), so "nobody asked in the latest run known in full" is
-  // [0] <= [1] - 2.  The host may be any number of runs ahead of the device; until it knows of a run, two passes.
+  // [0] <= [1] - 2.  The host may be any number of runs ahead of the device; until the first report (asked == 0) a run has
+  // one pass.  (Level 3 only: the other levels do not look at the words.)
   {
     const int asked = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[0] : 0;
     const int done = b->h_wait_hint ? reinterpret_cast<volatile int *>(b->h_wait_hint)[1] : 0;

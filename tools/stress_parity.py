@@ -242,6 +242,21 @@ def main():
             b.run_host(iq)
             ref = [r.copy() for r in b.collect()]
             b.close()
+            # level 4 (the default since round 5): deterministic -- two fresh batches, byte for byte
+            l4 = []
+            for rep in range(2):
+                b = lt.Batch(iq.shape[0], max(iq.shape[1], 9600), **kw)
+                b.set_scan_groups(args.scan_groups)
+                b.set_window_cache(4)
+                b.run_host(iq)
+                l4.append([x.copy() for x in b.collect()])
+                b.close()
+            n_variants += 1
+            for c in range(len(ref)):
+                if l4[0][c].tobytes() != l4[1][c].tobytes():
+                    bad.append({"seed": seed, "chain": c, "kw": kw, "what": "two level-4 runs of the same capture differ"})
+                    print(json.dumps(bad[-1]), file=sys.stderr, flush=True)
+                    break
             r = np.random.default_rng(seed * 13 + 5)
             for k in range(args.variants):
                 v = {"mode": int(r.integers(0, 2)), "cache": int(r.integers(0, 4)), "groups": int(r.integers(0, 4)),
