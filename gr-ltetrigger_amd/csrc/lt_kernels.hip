@@ -688,6 +688,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     p.n_counters = scan_counter_ints();
     p.keep_counter = kCtrList + (R.list_slot ? 0 : 1); // the other run's work-list counter (the cache's, behind them, are this run's)
     p.rebase = R.rebase;
+    p.reset_parts = R.reset_parts;
     // window cache for the scan rounds themselves: batches so small that a channel's strips are alone on their CUs
     // and a round is bound by a root wave's instruction stream -- without the transforms that stream is 330
     // instructions instead of 840
@@ -858,16 +859,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
 __global__ __launch_bounds__(256) void lt_reset_kernel(ChainState *state, int parts, int *rec_count)
 {
   if (rec_count && threadIdx.x == 0) rec_count[blockIdx.x] = 0;
-  uint32_t *w = reinterpret_cast<uint32_t *>(state + blockIdx.x);
-  // everything in front of the three average buffers; those are not cleared but declared zero (ema_zero = 2)
-  constexpr int n = (int)(offsetof(ChainState, avg) / 4);
-  constexpr int i_norm = (int)(offsetof(ChainState, m_norm_avg) / 4), i_ext = (int)(offsetof(ChainState, m_ext_avg) / 4);
-  constexpr int i_zero = (int)(offsetof(ChainState, ema_zero) / 4);
-  static_assert(offsetof(ChainState, avg) % 4 == 0, "ChainState is cleared word by word");
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const bool rec = i == i_norm || i == i_ext; // (the CFO ring is the per-chain kernel's: lt_chain_kernel.h)
-    if (parts & (rec ? 2 : 1)) w[i] = i == i_zero ? 2u : 0u;
-  }
+  reset_chain_states(state + blockIdx.x, 1, parts, threadIdx.x, 256);
 }
 hipError_t launch_reset(void *state, int n_chains, int parts, int *rec_count, hipStream_t stream)
 {

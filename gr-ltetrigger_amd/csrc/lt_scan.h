@@ -227,9 +227,12 @@ __device__ __forceinline__ void strip_resolve(const ema_t &e, int s, int lane, S
 
 // ---- the deferred form (scan rounds, round 5).  Eleven of a window's twelve lobe walks are thrown away: only the strip that
 // holds the window's peak needs its lobe.  A root wave of the scan therefore stops after the strip's maximum: it writes
-//   StripHead  m1, p1 -- the maximum over the owned lags and its lag --, far = the maximum over the owned lags OUTSIDE the 64
+//   StripHead  m1, p1 -- the maximum over the owned lags and its lag --, far = the maximum over the owned lags OUTSIDE the 32
 //              lags around p1, a0 (strip 0: the average of lag 0), 16 bytes;
-//   a row      the 64 lags p1 - 32 .. p1 + 31 themselves (halo lags included: the walk may cross the strip's boundary), 256 bytes
+//   a row      the 32 lags p1 - 16 .. p1 + 15 themselves (halo lags included: the walk may cross the strip's boundary), 128 bytes
+//              (a lobe that does not close within 14 lags to the right or 15 to the left -- the strips' own walk allowed 30 / 31 --
+//              sends the window to the exact path; lobes of the lag metric are 2-6 lags wide.  64-lag rows were measured first:
+//              twice the bytes written, HBM traffic 1.37 x algorithmic instead of 1.27 x, and a slower resolver)
 // and the resolver (one lane per window) walks the lobe of the ONE strip that holds the window's maximum, in the oracle's own
 // terms (oracle/lte_oracle.c:300-316): side-lobe maximum = the largest value outside [lb, ub) = max over the peak strip's far
 // and the owned lags of its row outside the lobe, and over the other strips' maxima -- or, for a neighbour whose maximum lies
@@ -243,9 +246,9 @@ struct StripHead {
 };
 static_assert(sizeof(StripHead) == 16, "StripHead layout");
 constexpr int32_t kHeadNoMax = 1 << 30; // no maximum found (a NaN in the average): the window goes to the exact path
-constexpr int kRowLags = 64;
+constexpr int kRowLags = 32, kRowHalf = kRowLags / 2;
 
-// -> the strip's head (wave-uniform), this lane's value of the row and its place in it (index i <-> lag p1 - 32 + i)
+// -> the strip's head (wave-uniform), this lane's value of the row and its place in it (index i <-> lag p1 - 16 + i; -1: none)
 __device__ __forceinline__ void strip_head_row(const ema_t &e, int s, int lane, StripHead &h, float &row, int &idx)
 {
   StripPeak k;
@@ -267,12 +270,14 @@ __device__ __forceinline__ void strip_head_row(const ema_t &e, int s, int lane, 
   float row_own;
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(row_own) : "v"(row), "v"(-FLT_MAX), "s"(sits_out));
   // outside the row a lane contributes its maximum -- or its second largest value where its maximum IS its row value
-  const float far_lane = (row_own == k.m) ? k.m2 : k.m;
+  // (the row: the lanes whose offset lies in [-16, 16); the other lanes' values of these two registers are not in it)
+  const bool in_row = (unsigned)(off + kRowHalf) < (unsigned)kRowLags;
+  const float far_lane = (in_row && row_own == k.m) ? k.m2 : k.m;
   h.m1 = k.M1;
   h.p1f = k.p1 | (k.flags ? kHeadNoMax : 0);
   h.far = wave_max_dpp(far_lane);
   h.a0 = (s == 0) ? rlane(e[0], kStripHalo) : 0.f;
-  idx = off + 32;
+  idx = in_row ? off + kRowHalf : -1; // (-1: not part of the row)
 }
 
 struct WindowResult {
@@ -415,7 +420,7 @@ __device__ __forceinline__ float strip_outside_lobe(const StripHead *__restrict_
   float v = h.far;
 #pragma unroll 1
   for (int i = 0; i < kRowLags; ++i) {
-    const int lag = p - 32 + i;
+    const int lag = p - kRowHalf + i;
     const float x = rows[s * kRowLags + i];
     if (lag_owned(s, lag) && (lag < lb || lag >= ub) && x > v) v = x;
   }
@@ -437,7 +442,7 @@ __device__ __forceinline__ WindowResult resolve_window_deferred(const StripHead 
       best = s;
     }
   }
-  // the peak strip's row, 64 values in registers (sixteen 16-byte loads in flight together)
+  // the peak strip's row, 32 values in registers (eight 16-byte loads in flight together)
   float r[kRowLags];
   {
     const v4f *rp = reinterpret_cast<const v4f *>(rows + best * kRowLags);
@@ -447,21 +452,26 @@ __device__ __forceinline__ WindowResult resolve_window_deferred(const StripHead 
       r[4 * q] = t.x; r[4 * q + 1] = t.y; r[4 * q + 2] = t.z; r[4 * q + 3] = t.w;
     }
   }
-  const StripHead hb = heads[best];
-  const int p1 = hb.p1f & ~kHeadNoMax;
+  // the peak strip's head out of the registers (a second trip to memory for heads[best] costs the wave ~2 us of latency)
+  v4f hb = h[0];
+#pragma unroll
+  for (int s = 1; s < kStrips; ++s) hb = best == s ? h[s] : hb;
+  const int p1f = __float_as_int(hb.y);
+  const int p1 = p1f & ~kHeadNoMax;
   WindowResult w;
-  w.exact = !(hb.p1f & kHeadNoMax);
+  w.exact = !(p1f & kHeadNoMax);
   w.peak_value = bm;
   w.peak_pos = (bm > -FLT_MAX) ? p1 : 0; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
   // main-lobe walk (oracle/lte_oracle.c:300-308): right while avg[u+1] <= avg[u] and u < 9727, left while avg[l-1] <= avg[l]
-  // and l > 1; no left walk for a peak at lag <= 2.  Row index 32 is the peak; offsets beyond +-30 / 31: not closed here.
+  // and l > 1; no left walk for a peak at lag <= 2.  Row index 16 is the peak; offsets beyond +14 / -15: not closed here.
+  constexpr int C = kRowHalf;
   uint32_t mr = 0u, ml = 0u;
 #pragma unroll
-  for (int j = 1; j <= 30; ++j)
-    if (!(r[32 + j + 1] <= r[32 + j]) || p1 + j >= kConvLen - 1) mr |= 1u << j;
+  for (int j = 1; j <= C - 2; ++j)
+    if (!(r[C + j + 1] <= r[C + j]) || p1 + j >= kConvLen - 1) mr |= 1u << j;
 #pragma unroll
-  for (int j = 1; j <= 31; ++j)
-    if (!(r[32 - j - 1] <= r[32 - j]) || p1 - j <= 1) ml |= 1u << j;
+  for (int j = 1; j <= C - 1; ++j)
+    if (!(r[C - j - 1] <= r[C - j]) || p1 - j <= 1) ml |= 1u << j;
   int j_r = 1, j_l = 1;
   if (mr) j_r = __builtin_ctz(mr);
   else w.exact = false;
@@ -470,10 +480,10 @@ __device__ __forceinline__ WindowResult resolve_window_deferred(const StripHead 
   else w.exact = false;
   const int lb = p1 - j_l, ub = p1 + j_r;
   // the largest value outside [lb, ub): the peak strip's own share ...
-  float out = hb.far;
+  float out = hb.z;
 #pragma unroll
   for (int i = 0; i < kRowLags; ++i) {
-    const int lag = p1 - 32 + i;
+    const int lag = p1 - kRowHalf + i;
     const bool counts = lag_owned(best, lag) && (lag < lb || lag >= ub);
     const float x = counts ? r[i] : -FLT_MAX;
     out = x > out ? x : out;
@@ -489,8 +499,7 @@ __device__ __forceinline__ WindowResult resolve_window_deferred(const StripHead 
   }
   // empty ranges stand for their first element: the left one is empty exactly when the peak sits at lag <= 2,
   // the right one when the lobe reaches lag 9726 (avg[9726..9727] = 0)
-  float sl = out;
-  if (w.peak_pos <= 2) sl = heads[0].a0;
+  const float sl = (w.peak_pos <= 2) ? h[0].w : out;
   const float sr = (ub >= kNLags) ? 0.f : out;
   const float side = sl > sr ? sl : sr;
   w.psr = w.peak_value / side;

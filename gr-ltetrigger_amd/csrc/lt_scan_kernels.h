@@ -114,7 +114,7 @@ struct ScanArgs {
   int jobs_cap;
   ChainState *state;   // [n_channels * 3]
   StripHead *heads;    // [n_channels * 3][kScanMaxRound][12]: what a strip says about a window (lt_scan.h, the deferred form) ...
-  float *rows;         // [n_channels * 3][kScanMaxRound][12][64]: ... and the 64 lags around its maximum
+  float *rows;         // [n_channels * 3][kScanMaxRound][12][32]: ... and the 32 lags around its maximum
   const DeviceTables *tab;
   unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
   const float *cache;       // window cache (slots of kStrips x 64 * kStripRegs floats), or null
@@ -332,7 +332,7 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
         float row;
         int idx;
         strip_head_row(ema, strip, ln, hd, row, idx);
-        rows[(int64_t)(k - sq.n_a) * (kStrips * kRowLags) + idx] = row;
+        if (idx >= 0) rows[(int64_t)(k - sq.n_a) * (kStrips * kRowLags) + idx] = row;
         if (lane == 0) heads[(int64_t)(k - sq.n_a) * kStrips] = hd;
       }
     }
@@ -430,7 +430,7 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
         float row;
         int idx;
         strip_head_row(ema, strip, ln, hd, row, idx);
-        rows[(int64_t)(k - sq.n_a) * (kStrips * kRowLags) + idx] = row;
+        if (idx >= 0) rows[(int64_t)(k - sq.n_a) * (kStrips * kRowLags) + idx] = row;
         if (lane == 0) heads[(int64_t)(k - sq.n_a) * kStrips] = hd;
       }
       LT_PSTAMP(7) // resolve + store
@@ -470,6 +470,8 @@ struct PlanArgs {
   int call_reach;    // kCallReach (lt_chain_kernel.h)
   // first launch of a run only (first_round): counters to clear behind n_jobs, the one to leave alone, positions to 0
   int n_counters, keep_counter, rebase;
+  int reset_parts;   // ... and lt_batch_reset, applied here instead of in a launch of its own (lt_reset_kernel's rule: bit 0 =
+                     // everything in front of the averages but the CP averages, bit 1 = those; 0 = no reset pending)
   // window cache for the scan rounds (small batches): every job's windows get slots, lt_metric_kernel fills them
   // before the round's scan.  round_slots counts the slots handed out in this round, from 0 in every round (never past
   // slot_cap).
@@ -670,6 +672,24 @@ __device__ __forceinline__ void fill_job_slots(const PlanArgs &a, const ScanJob 
   }
 }
 
+// lt_batch_reset: the chains back to their constructor state -- everything in front of the three average buffers; those are
+// not cleared but declared zero (ema_zero = 2).  The members only the per-record kernels touch (the CP averages; the CFO ring
+// is the per-chain kernel's) are parts bit 1, the rest bit 0 (with lt_batch_set_overlap the two are cleared on different streams).
+__device__ __forceinline__ void reset_chain_states(ChainState *state, int n_chains, int parts, int tid, int nthreads)
+{
+  constexpr int n = (int)(offsetof(ChainState, avg) / 4);
+  constexpr int i_norm = (int)(offsetof(ChainState, m_norm_avg) / 4), i_ext = (int)(offsetof(ChainState, m_ext_avg) / 4);
+  constexpr int i_zero = (int)(offsetof(ChainState, ema_zero) / 4);
+  static_assert(offsetof(ChainState, avg) % 4 == 0, "ChainState is cleared word by word");
+  for (int c = 0; c < n_chains; ++c) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(state + c);
+    for (int i = tid; i < n; i += nthreads) {
+      const bool rec = i == i_norm || i == i_ext;
+      if (parts & (rec ? 2 : 1)) w[i] = i == i_zero ? 2u : 0u;
+    }
+  }
+}
+
 // The run's first launch: one workgroup.  It first brings the run's counters to zero (the job counters of every round
 // and this run's work-list counter; `keep` is the other run's, which its per-record kernels may still be using) and,
 // for a run that is a capture of its own, the chains' positions; then it plans the first round.
@@ -678,6 +698,7 @@ __global__ __launch_bounds__(256) void lt_plan_kernel(PlanArgs a)
   if (a.first_round) {
     for (int i = threadIdx.x; i < a.n_counters; i += 256)
       if (i != a.keep_counter) a.n_jobs[i] = 0;
+    if (a.reset_parts) reset_chain_states(a.state, a.n_channels * 3, a.reset_parts, threadIdx.x, 256);
     if (a.rebase)
       for (int i = threadIdx.x; i < a.n_channels * 3; i += 256) a.state[i].pos = 0;
     // (one workgroup: what it has just stored is read back -- by other threads, and through atomics that execute in the

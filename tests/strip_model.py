@@ -164,8 +164,13 @@ def find_strips(avg):
 
 # ---------------------------------------------------------------- the deferred form (scan rounds since round 5)
 # A root wave stops after the strip's maximum: it leaves a head (m1, p1, far = the maximum over its owned lags outside
-# the 64 lags around p1, a0) and the row of those 64 lags; the resolver walks the lobe of the one strip that holds the
-# window's peak (strip_head_row / resolve_window_deferred in csrc/lt_scan.h).
+# the 32 lags around p1, a0) and the row of those 32 lags; the resolver walks the lobe of the one strip that holds the
+# window's peak (strip_head_row / resolve_window_deferred in csrc/lt_scan.h).  A lobe that does not close within 14 lags
+# to the right or 15 to the left sends the window to the exact path.
+ROW = 32
+HALF = ROW // 2
+
+
 def strip_head_row(avg, s):
     e, lag = strip_regs(avg, s)
     c0 = PITCH * s - HALO
@@ -190,9 +195,10 @@ def strip_head_row(avg, s):
     use_b = d != offs
     row = np.where(use_b, e[r_b], e[r_p])
     row_own = np.where(use_b, masked[r_b], masked[r_p])  # -FLT_MAX where the lag is not the strip's own
-    far_lane = np.where(row_own == m, m2, m)
-    out_row = np.zeros(64, np.float32)
-    out_row[offs + 32] = row
+    in_row = (offs >= -HALF) & (offs < HALF)
+    far_lane = np.where(in_row & (row_own == m), m2, m)
+    out_row = np.zeros(ROW, np.float32)
+    out_row[offs[in_row] + HALF] = row[in_row]
     a0 = np.float32(e[0][HALO]) if s == 0 else np.float32(0)
     return dict(m1=np.float32(m1), p1=int(p1), far=np.float32(far_lane.max()), a0=a0, row=out_row, s=s)
 
@@ -203,8 +209,8 @@ def _owned(s, lag):
 
 def _outside(h, lb, ub):
     v = h["far"]
-    for i in range(64):
-        lag = h["p1"] - 32 + i
+    for i in range(ROW):
+        lag = h["p1"] - HALF + i
         if _owned(h["s"], lag) and (lag < lb or lag >= ub) and h["row"][i] > v:
             v = h["row"][i]
     return v
@@ -219,11 +225,11 @@ def combine_deferred(heads):
     p1, r = hb["p1"], hb["row"]
     peak_value = hb["m1"]
     peak = p1 if peak_value > -FLT_MAX else 0
-    j_r = next((j for j in range(1, 31) if (not r[32 + j + 1] <= r[32 + j]) or p1 + j >= CONV_LEN - 1), None)
+    j_r = next((j for j in range(1, HALF - 1) if (not r[HALF + j + 1] <= r[HALF + j]) or p1 + j >= CONV_LEN - 1), None)
     if p1 <= 2:
         j_l = p1
     else:
-        j_l = next((j for j in range(1, 32) if (not r[32 - j - 1] <= r[32 - j]) or p1 - j <= 1), None)
+        j_l = next((j for j in range(1, HALF) if (not r[HALF - j - 1] <= r[HALF - j]) or p1 - j <= 1), None)
     if j_r is None or j_l is None:
         return None
     lb, ub = p1 - j_l, p1 + j_r

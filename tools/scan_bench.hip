@@ -171,8 +171,8 @@ int main(int argc, char **argv)
           }
     printf("checksum of the heads (roots %d, %d sequences): %016llx   of the rows: %016llx\n", roots, n_seq, sum, rsum);
     for (int i = 0; i < 24; ++i)
-      printf("head[%d]: m1=%g p1=%d far=%g a0=%g  row[30..34]=%g %g %g %g %g\n", i, heads[i].m1, heads[i].p1f, heads[i].far, heads[i].a0, rows[(size_t)i * kRowLags + 30],
-             rows[(size_t)i * kRowLags + 31], rows[(size_t)i * kRowLags + 32], rows[(size_t)i * kRowLags + 33], rows[(size_t)i * kRowLags + 34]);
+      printf("head[%d]: m1=%g p1=%d far=%g a0=%g  row[14..18]=%g %g %g %g %g\n", i, heads[i].m1, heads[i].p1f, heads[i].far, heads[i].a0, rows[(size_t)i * kRowLags + kRowHalf - 2],
+             rows[(size_t)i * kRowLags + kRowHalf - 1], rows[(size_t)i * kRowLags + kRowHalf], rows[(size_t)i * kRowLags + kRowHalf + 1], rows[(size_t)i * kRowLags + kRowHalf + 2]);
   }
   return 0;
 }
