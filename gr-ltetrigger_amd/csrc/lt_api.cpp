@@ -180,6 +180,10 @@ struct lt_batch {
   bool ev_timed = false;           // the last run recorded its first and last event
   int last_launches = 0;           // kernel launches the last run enqueued (lt_batch_last_launch_count)
   bool ran = false;
+  // lt_batch_collect's landing area: pinned (a copy into pageable memory goes through the runtime's own staging buffer, a
+  // second copy and ~100 us per call: what a 10 ms chunk of a stream pays once per chunk); the vectors only if pinning fails
+  lt_record *h_recs_pin = nullptr;
+  int *h_count_pin = nullptr;
   std::vector<lt_record> h_recs;
   std::vector<int> h_count;
   // lt_batch_set_overlap: the per-record kernels of a run on a stream of their own, beside the next run's scan rounds.
@@ -624,6 +628,8 @@ int lt_batch_create(lt_batch **out, int device, int n_channels, int64_t max_samp
     } else {
       (void)hipGetLastError();
       if (b->h_wait_hint) (void)hipHostFree(b->h_wait_hint);
+  if (b->h_recs_pin) (void)hipHostFree(b->h_recs_pin);
+  if (b->h_count_pin) (void)hipHostFree(b->h_count_pin);
       b->h_wait_hint = nullptr;
       b->d_wait_hint = nullptr;
     }
@@ -810,6 +816,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
     // always -- at level 4 a search out of a stream and one through the transforms differ in the low bits of PSR, so which of
     // the two a run takes is decided by the chains' state on the device alone (pass 0), never by the host's cue
     R.two_pass = b->use_cache != 3 || !b->h_wait_hint || (asked > 0 && asked > done - 2);
+    R.ask_early = b->use_cache != 3 && b->use_cache != 0; // (level 3's second pass hangs on pass 0's report to the host)
     if (b->n_runs == 0x3fffffff && b->h_wait_hint) b->h_wait_hint[0] = b->h_wait_hint[1] = 0; // (the run numbers wrap)
   }
   const int slot = (int)(b->n_runs % lt_batch::kPhaseRing);
@@ -901,6 +908,33 @@ int lt_batch_last_kernel_ms(lt_batch *b, float *ms)
   return LT_OK;
 }
 
+namespace {
+// -> where the device's records and counts land on the host (pinned if it can be had)
+void collect_area(lt_batch *b, lt_record **recs, int **count)
+{
+  const size_t nchains = (size_t)b->n_channels * 3;
+  if (!b->h_recs_pin && b->h_recs.empty()) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&b->h_recs_pin), sizeof(lt_record) * nchains * (size_t)b->rec_cap, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&b->h_count_pin), sizeof(int) * nchains, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      if (b->h_recs_pin) (void)hipHostFree(b->h_recs_pin);
+      if (b->h_count_pin) (void)hipHostFree(b->h_count_pin);
+      b->h_recs_pin = nullptr;
+      b->h_count_pin = nullptr;
+    }
+  }
+  if (b->h_recs_pin) {
+    *recs = b->h_recs_pin;
+    *count = b->h_count_pin;
+    return;
+  }
+  b->h_count.resize(nchains);
+  b->h_recs.resize(nchains * (size_t)b->rec_cap);
+  *recs = b->h_recs.data();
+  *count = b->h_count.data();
+}
+} // namespace
+
 int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_t *counts)
 {
   if (!b || !counts || (cap_per_chain > 0 && !recs)) return fail(LT_ERROR_INVALID_INPUTS, "null argument");
@@ -912,19 +946,17 @@ int lt_batch_collect(lt_batch *b, lt_record *recs, int64_t cap_per_chain, int64_
     b->side_busy = false;
   }
   const size_t nchains = (size_t)b->n_channels * 3;
-  b->h_count.resize(nchains);
-  b->h_recs.resize(nchains * (size_t)b->rec_cap);
-  HIP_TRY(hipMemcpyAsync(b->h_count.data(), b->cur_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(b->h_recs.data(), b->cur_recs, sizeof(lt_record) * b->h_recs.size(),
-                         hipMemcpyDeviceToHost, s));
+  lt_record *hr = nullptr;
+  int *hc = nullptr;
+  collect_area(b, &hr, &hc);
+  HIP_TRY(hipMemcpyAsync(hc, b->cur_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hr, b->cur_recs, sizeof(lt_record) * nchains * (size_t)b->rec_cap, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (size_t c = 0; c < nchains; ++c) {
-    int64_t n = b->h_count[c];
+    int64_t n = hc[c];
     counts[c] = n;
     if (n > cap_per_chain) n = cap_per_chain;
-    if (n > 0)
-      memcpy(recs + c * (size_t)cap_per_chain, b->h_recs.data() + c * (size_t)b->rec_cap,
-             sizeof(lt_record) * (size_t)n);
+    if (n > 0) memcpy(recs + c * (size_t)cap_per_chain, hr + c * (size_t)b->rec_cap, sizeof(lt_record) * (size_t)n);
   }
   return LT_OK;
 }
@@ -943,18 +975,17 @@ int lt_batch_collect_previous(lt_batch *b, lt_record *recs, int64_t cap_per_chai
   // that run's per-record kernels are through when its event is (the last run's may still be under way)
   HIP_TRY(hipStreamWaitEvent(b->copy, b->rec_done[set], 0));
   const size_t nchains = (size_t)b->n_channels * 3;
-  b->h_count.resize(nchains);
-  b->h_recs.resize(nchains * (size_t)b->rec_cap);
-  HIP_TRY(hipMemcpyAsync(b->h_count.data(), set ? b->d_count_b : b->d_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, b->copy));
-  HIP_TRY(hipMemcpyAsync(b->h_recs.data(), set ? b->d_recs_b : b->d_recs, sizeof(lt_record) * b->h_recs.size(),
-                         hipMemcpyDeviceToHost, b->copy));
+  lt_record *hr = nullptr;
+  int *hc = nullptr;
+  collect_area(b, &hr, &hc);
+  HIP_TRY(hipMemcpyAsync(hc, set ? b->d_count_b : b->d_count, sizeof(int) * nchains, hipMemcpyDeviceToHost, b->copy));
+  HIP_TRY(hipMemcpyAsync(hr, set ? b->d_recs_b : b->d_recs, sizeof(lt_record) * nchains * (size_t)b->rec_cap, hipMemcpyDeviceToHost, b->copy));
   HIP_TRY(hipStreamSynchronize(b->copy));
   for (size_t c = 0; c < nchains; ++c) {
-    int64_t n = b->h_count[c];
+    int64_t n = hc[c];
     counts[c] = n;
     if (n > cap_per_chain) n = cap_per_chain;
-    if (n > 0)
-      memcpy(recs + c * (size_t)cap_per_chain, b->h_recs.data() + c * (size_t)b->rec_cap, sizeof(lt_record) * (size_t)n);
+    if (n > 0) memcpy(recs + c * (size_t)cap_per_chain, hr + c * (size_t)b->rec_cap, sizeof(lt_record) * (size_t)n);
   }
   return LT_OK;
 }

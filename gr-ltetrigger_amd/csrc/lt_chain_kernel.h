@@ -66,9 +66,8 @@ struct ChainArgs {
                        // the host's cue to give the next runs two passes or one
   int stream;          // window cache level 4: an untracked chain asks for its lag-metric STREAM instead of windows (below)
 };
-constexpr int kCacheStripLags = 64 * kStripRegs;   // 896 floats per (slot, strip)
-constexpr int kCacheMinSearches = 6;               // fewer searches ahead than this: not worth a pass of its own
-constexpr int kCacheMaxPerChain = 256;
+// (kCacheStripLags, kCacheMinSearches, kCacheMaxPerChain, kStreamBlock / kStreamSlot / kStreamBack: lt_scan_kernels.h -- the last
+// resolve launch of a run makes the chains' cache requests with them, chain_request_cache)
 __host__ __device__ constexpr size_t cache_slot_floats() { return (size_t)kStrips * kCacheStripLags; }
 
 struct SearchResult {
@@ -222,10 +221,6 @@ __device__ __forceinline__ SearchResult chain_search_resolve(Lds &L, int w, int 
 // The stream's blocks are not the window's strips: the same sums in another order of rounding.  Level 4 is therefore
 // NOT bit-identical to levels 0..3 (which are, among themselves); it matches them, and the oracle, to the tolerance the
 // parity tests give the device's own transform against the oracle's (tests/test_gpu_stream.py).
-constexpr int kStreamBlock = kCacheStripLags;           // 896 stream elements per block = per (slot, strip)
-constexpr int kStreamSlot = kStrips * kStreamBlock;     // 10752 per slot
-constexpr int kStreamBack = 1024;                       // the stream starts this far in front of the chain's position:
-                                                        // one hit moves the grid back by at most 960
 constexpr int kEdgeHead = kSymbolSz - 1;                // lags 0..126: the sum stops at the window's first sample
 constexpr int kEdgeTail = kNLags - kHalfFrame;          // lags 9600..9725: ... at its last
 constexpr int kEdgeShare = kChainWaves / 2;             // lanes (in as many waves) that share the 128 products of a pair of edge lags

@@ -626,6 +626,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
   StripHead *parts = reinterpret_cast<StripHead *>(R.parts);
   float *part_rows = parts ? reinterpret_cast<float *>(parts + (size_t)n_chains * kScanMaxRound * kStrips) : nullptr;
   const int64_t t1 = R.t0 + R.n;
+  bool ask_early = false; // the last resolve launch makes the chains' cache requests (below)
   // ---- rounds of plan, scan, resolve.  An idle chain needs one round per `seg_len` windows; a chain that fires
   // needs a few more (a round ends for it where it re-aligns, where tracking starts, where it is lost).  Rounds
   // with nothing left to do cost three empty launches; whatever a chain has not got through after the last one --
@@ -646,6 +647,13 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     q.state = state; q.heads = parts; q.rows = part_rows; q.recs = R.recs; q.rec_cap = R.rec_cap;
     q.rec_count = R.rec_count; q.t1 = t1; q.flush = R.flush; q.call_reach = kCallReach; q.psr_threshold = R.psr_threshold;
     q.track_after = R.track_after; q.track_every = R.track_every;
+    // the chains' requests for the window cache by the last resolve launch instead of a first pass of the per-chain kernel
+    // (levels 1, 2, 4 with the cache there and the rounds on; level 3 -- R.two_pass from the host's cue -- keeps its pass 0)
+    const bool cache_ok = R.cache && R.slot_owner && R.slot_pos && R.slot_cap > 0 && R.slot_quota >= kCacheMinSearches && R.cache_level >= 1 && R.two_pass;
+    ask_early = cache_ok && R.ask_early && R.scan && parts;
+    q.ask = 0; q.ask_stream = R.stream ? 1 : 0; q.slot_quota = R.slot_quota;
+    q.slot_owner = reinterpret_cast<int2 *>(R.slot_owner); q.slot_pos = reinterpret_cast<int64_t *>(R.slot_pos);
+    q.slot_next = R.n_jobs + kCtrSlots; q.launch_slots = R.n_jobs + kCtrLaunchSlots + kMaxRounds + 1;
     const int seg_first = R.seg_first < 1 ? 1 : R.seg_first > kScanMaxRound ? kScanMaxRound : R.seg_first;
     const int64_t windows = (R.n + R.hist_len) / kHalfFrame + 1;
     int seg_len = R.seg_len > kScanMaxRound ? kScanMaxRound : R.seg_len;
@@ -711,6 +719,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
       s.jobs = q.jobs = jobs2[r & 1];
       s.n_jobs = R.n_jobs + 2 * r;
       q.plan_next = r + 1 < rounds;
+      q.ask = (!q.plan_next && ask_early) ? 1 : 0;
       q.next = p;
       q.next.first_round = 0;
       q.next.round_windows = seg_len;
@@ -797,7 +806,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     c.run_id = R.run_id;
     if (!(c.cache && c.slot_owner && c.slot_pos && c.slot_cap > 0 && c.slot_quota >= kCacheMinSearches && R.cache_level >= 1 && R.two_pass)) c.cache = nullptr;
     c.stream = R.stream && c.cache;
-    LT_LAUNCH(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c);
+    if (!(ask_early && c.cache)) LT_LAUNCH(lt_chain_kernel, dim3(n_chains), dim3(kChainThreads), 0, stream, c); // pass 0 (or the only pass)
     if (c.cache) {
       // the lag metric of the windows pass 0 has asked for, chip-wide; then the chains that waited for it
       MetricArgs m;

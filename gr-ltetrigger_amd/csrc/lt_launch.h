@@ -61,6 +61,8 @@ struct RunLaunch {
                               // enough searches ahead of it to ask for the window cache, and of the last run the per-chain kernel ran in
   int run_id = 0;             // this run's number (from 1)
   int stream = 0;             // window cache level 4: untracked chains ask for their lag-metric stream (lt_chain_kernel.h)
+  int ask_early = 0;          // with the rounds on and the cache there: the chains' cache requests are made by the run's last resolve
+                              // launch, the per-chain kernel runs once behind lt_metric_kernel (no pass 0 launch)
   int two_pass = 1;           // 0: the per-chain kernel in one pass without the cache (no lt_metric_kernel, no second launch):
                               // no chain asked in the latest run the caller knows in full.  Timing only, never a record
   int *n_launches = nullptr;  // host: out, the number of kernel launches the run enqueued

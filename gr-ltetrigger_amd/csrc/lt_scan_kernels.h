@@ -102,6 +102,14 @@ constexpr int scan_wg_per_job(int G) { return kStrips / G; }
 #define LT_POLL_SLEEP 1 // s_sleep units (64 clocks) between two looks at a hand-over counter
 #endif
 constexpr int kScanMaxRound = 128;           // windows per job and round at most (one resolver lane each)
+// ---- window cache (lt_chain_kernel.h): sizes of a request
+constexpr int kCacheStripLags = 64 * kStripRegs;   // 896 floats per (slot, strip)
+constexpr int kCacheMinSearches = 6;               // fewer searches ahead than this: not worth a pass of its own
+constexpr int kCacheMaxPerChain = 256;
+constexpr int kStreamBlock = kCacheStripLags;           // 896 stream elements per block = per (slot, strip)
+constexpr int kStreamSlot = kStrips * kStreamBlock;     // 10752 per slot
+constexpr int kStreamBack = 1024;                       // the stream starts this far in front of the chain's position:
+                                                        // one hit moves the grid back by at most 960
 
 struct ScanArgs {
   const v2f *iq;       // [n_channels][ch_stride]
@@ -744,6 +752,16 @@ struct ResolveArgs {
   int track_every;
   PlanArgs next;      // the plan of the next round, made by the same launch (next.jobs / next.n_jobs: the other buffers)
   int plan_next;
+  // the run's LAST resolve launch (plan_next == 0) with the window cache on: every chain's request for the cache -- what pass 0
+  // of lt_chain_kernel would ask for -- is made here, from the state the rounds leave, so that the per-chain kernel runs once,
+  // behind lt_metric_kernel (one launch fewer per run; levels 1, 2 and 4 -- level 3 keeps its host cue and its pass 0)
+  int ask;            // 0 = no requests here
+  int ask_stream;     // level 4: untracked chains ask for their lag-metric stream
+  int slot_quota;
+  int2 *slot_owner;
+  int64_t *slot_pos;
+  int *slot_next;     // (+3: chains that asked, diagnostics)
+  int *launch_slots;
 };
 
 __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, int lane)
@@ -1081,6 +1099,73 @@ __device__ __forceinline__ void resolve_chain(const ResolveArgs &a, int chain, i
   }
 }
 
+// What pass 0 of lt_chain_kernel asks of the window cache (lt_chain_kernel.h: chain_run, "pass 0 of two"), by the chain's wave
+// of the last resolve launch: a chain with kCacheMinSearches or more searches ahead of it -- all on the grid it stands on,
+// unless a hit moves it -- lists its coming windows (every window from pos for an idle or acquiring chain, every
+// (track_every + 1)-th for a tracked one) or, at level 4 and untracked, its lag-metric stream; the slots are its own
+// (chain * slot_quota + k), the work list's order is whatever the atomics make it.  Same arithmetic as pass 0: same requests.
+__device__ __forceinline__ void chain_request_cache(const ResolveArgs &a, int chain, int lane)
+{
+  ChainState *st = a.state + chain;
+  // (lane 0 reads what a lane 0 has written -- this wave's a moment ago, or an earlier launch's -- and hands it round)
+  int done = 0, tracking = 0, timer = 0, pre_n = 0, nrec = 0;
+  int64_t pos = 0, pre_pos = 0;
+  if (lane == 0) {
+    done = st->run_done; tracking = st->is_tracking; timer = st->timer; pre_n = st->pre_n; nrec = a.rec_count[chain];
+    pos = st->pos; pre_pos = st->pre_pos;
+  }
+  done = uniform_i32(done); tracking = uniform_i32(tracking); timer = uniform_i32(timer); pre_n = uniform_i32(pre_n);
+  nrec = uniform_i32(nrec); pos = uniform_i64(pos); pre_pos = uniform_i64(pre_pos);
+  if (done) return;
+  const bool callable = (a.flush ? pos + kHalfFrame <= a.t1 : pos + a.call_reach <= a.t1) && nrec < a.rec_cap;
+  if (!callable) return;
+  const int stride = tracking ? a.track_every + 1 : 1;
+  const int64_t first = pos + (tracking ? (int64_t)timer * kHalfFrame : 0);
+  const int64_t last_start = a.flush ? a.t1 - kHalfFrame : a.t1 - a.call_reach; // last position a call may start at
+  int64_t ahead = first <= last_start ? (last_start - first) / ((int64_t)stride * kHalfFrame) + 1 : 0;
+  if (ahead > kCacheMaxPerChain) ahead = kCacheMaxPerChain;
+  if (a.ask_stream && ahead >= kCacheMinSearches && !tracking) {
+    int64_t o = first - kStreamBack;
+    if (pre_n > 0 && pre_pos < o) o = pre_pos;
+    int64_t want = (last_start + kNLags - o + kStreamSlot - 1) / kStreamSlot;
+    if (want > kCacheMaxPerChain) want = kCacheMaxPerChain;
+    const int got = a.slot_quota < (int)want ? a.slot_quota : (int)want;
+    if (got >= 2) {
+      int wi = 0;
+      if (lane == 0) wi = atomicAdd(a.slot_next, got);
+      wi = uniform_i32(wi);
+      for (int i = lane; i < got; i += 64) {
+        a.slot_owner[wi + i] = make_int2(chain, -1 - i); // (second member negative: a slot of a stream)
+        a.slot_pos[wi + i] = o + (int64_t)i * kStreamSlot;
+      }
+      if (lane == 0) {
+        atomicAdd(a.launch_slots, got);
+        atomicAdd(a.slot_next + 3, 1); // diagnostics
+        st->cache_pos = o; st->cache_base = chain * a.slot_quota; st->cache_n = got; st->cache_stride = 0; // (0: a stream)
+      }
+      return;
+    }
+    ahead = 0; // (no room: nothing to ask for)
+  }
+  if (ahead >= kCacheMinSearches) {
+    const int got = a.slot_quota < (int)ahead ? a.slot_quota : (int)ahead;
+    if (got >= kCacheMinSearches) {
+      int wi = 0;
+      if (lane == 0) wi = atomicAdd(a.slot_next, got);
+      wi = uniform_i32(wi);
+      for (int i = lane; i < got; i += 64) {
+        a.slot_owner[wi + i] = make_int2(chain, i);
+        a.slot_pos[wi + i] = first + (int64_t)i * stride * kHalfFrame;
+      }
+      if (lane == 0) {
+        atomicAdd(a.launch_slots, got);
+        atomicAdd(a.slot_next + 3, 1); // diagnostics
+        st->cache_pos = first; st->cache_base = chain * a.slot_quota; st->cache_n = got; st->cache_stride = stride;
+      }
+    }
+  }
+}
+
 // One workgroup per channel, one wave per chain; when the three chains are through, the channel's jobs of the
 // next round are planned by the same launch.
 __global__ __launch_bounds__(192) void lt_resolve_kernel(ResolveArgs a)
@@ -1088,7 +1173,10 @@ __global__ __launch_bounds__(192) void lt_resolve_kernel(ResolveArgs a)
   const int c = blockIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   resolve_chain(a, c * 3 + w, lane);
-  if (!a.plan_next) return;
+  if (!a.plan_next) {
+    if (a.ask) chain_request_cache(a, c * 3 + w, lane);
+    return;
+  }
   __threadfence_block();
   __syncthreads();
   __shared__ ScanJob *planned;
