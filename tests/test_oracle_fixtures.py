@@ -168,3 +168,36 @@ def test_first_cell_of_a_channel_is_the_fixture_cell(oracle):
     assert cell == (expect["cell_id"], expect["nof_prb"], 1)
     quiet = oracle.batch_run(iq[None, :], psr_threshold=1e9, nthreads=3)
     assert bench.first_cell(quiet[0:3], hf_of(quiet), M.decode_mib, oracle) is None
+
+
+def test_compare_chain_records_every_tie_and_excuses_only_tiny_gaps(oracle, frames_192):
+    """oracle.compare_chain (the comparison bench.py, tools/stress_parity.py and the full-size GPU tests use): records on the
+    parity bar pass; a different peak position is excused only if the two lags' averages differ by at most 1e-5 relative in
+    the oracle's own average at that call -- and the gap is reported either way; any other difference fails."""
+    x = frames_192["6prb"]
+    want = oracle.chain_run(x, 0)
+    assert oracle.compare_chain(want.copy(), want, x, 0) == (True, None)
+    # a metric field inside the tolerance passes, outside it fails
+    got = want.copy()
+    got["psr"] *= np.float32(1.00005)
+    assert oracle.compare_chain(got, want, x, 0) == (True, None)
+    got["psr"] *= np.float32(1.001)
+    assert oracle.compare_chain(got, want, x, 0)[0] is False
+    # a peak position that is NOT a near-tie: fails, with the (large) gap on record
+    call = int(np.nonzero(want["flags"] & oracle.F_SEARCHED)[0][0])
+    got = want.copy()
+    got["peak_pos"][call] = (int(want["peak_pos"][call]) + 4000) % 9000
+    ok, tie = oracle.compare_chain(got, want, x, 0)
+    assert ok is False and tie["call"] == call and tie["gap"] > 1e-3 and tie["lag_oracle"] == int(want["peak_pos"][call])
+    # a true twin: a lag whose average equals the peak's bit for bit is excused (gap 0) -- only up to that call is compared
+    avg_gap = oracle.argmax_tie_gap(x, 0, want, call, int(want["peak_pos"][call]))
+    assert avg_gap == 0.0
+    got = want.copy()
+    got["peak_pos"][call] = int(want["peak_pos"][call])  # same lag: no difference at all
+    assert oracle.compare_chain(got, want, x, 0) == (True, None)
+    # an index field other than the peak position never counts as a tie
+    got = want.copy()
+    got["score"][call] += 1
+    assert oracle.compare_chain(got, want, x, 0) == (False, None)
+    # a missing record fails
+    assert oracle.compare_chain(want[:-1], want, x, 0)[0] is False
