@@ -732,7 +732,6 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
     b->side_busy = false;
   }
   if (ov && b->rec_done_valid[set]) HIP_TRY(hipStreamWaitEvent(s, b->rec_done[set], 0)); // this set's last user, two runs ago
-  int reset_in_plan = 0;
   if (b->pending_reset) {
     int *count = set ? b->d_count_b : b->d_count; // (this set's record counts: cleared by the same launch)
     if (ov) { // the per-record kernels' members on their stream, behind the previous run's
@@ -741,7 +740,7 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
       b->side_busy = true;
     } else {
       // (measured and dropped, round 5: the run's first launch -- lt_plan_kernel, a single workgroup -- clearing the state
-      // itself, RunLaunch::reset_parts: one workgroup takes 32 us for the 83 K words 192 workgroups clear in 4.8)
+      // itself: one workgroup takes 32 us for the 83 K words 192 workgroups clear in 4.8)
       HIP_TRY(lt::launch_reset(b->d_state, (int)nchains, 3, count, s));
     }
     b->pending_reset = false;
@@ -777,7 +776,6 @@ int batch_chunk(lt_batch *b, const lt_cf32 *iq, int iq_on_device, int64_t n_samp
   R.rec_count = set ? b->d_count_b : b->d_count;
   R.list_slot = set;
   R.rebase = restart ? 1 : 0;
-  R.reset_parts = reset_in_plan;
   R.out_hf = b->d_hf;
   R.out_cap = (int)b->hf_cap;
   R.tab = b->tab;

@@ -696,7 +696,6 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     p.n_counters = scan_counter_ints();
     p.keep_counter = kCtrList + (R.list_slot ? 0 : 1); // the other run's work-list counter (the cache's, behind them, are this run's)
     p.rebase = R.rebase;
-    p.reset_parts = R.reset_parts;
     // window cache for the scan rounds themselves: batches so small that a channel's strips are alone on their CUs
     // and a round is bound by a root wave's instruction stream -- without the transforms that stream is 330
     // instructions instead of 840

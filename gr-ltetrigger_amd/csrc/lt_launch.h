@@ -48,7 +48,6 @@ struct RunLaunch {
   hipEvent_t ev_scan_done = nullptr;  // optional: recorded after the last scan segment / after the per-chain kernel
   hipEvent_t ev_chain_done = nullptr; // (required when the per-record kernels go to a stream of their own)
   int rebase = 0;             // the run is a capture of its own: the chains' positions restart at 0
-  int reset_parts = 0;        // lt_batch_reset pending: the run's first launch clears the chain state (launch_reset's parts), no launch of its own
   void *cache = nullptr;      // device, slot_cap x cache_slot_bytes(): the window cache (lag metrics formed in bulk for the chains the
                               // scan rounds leave to the per-chain kernel); null: no cache, the per-chain kernel runs once
   void *slot_owner = nullptr; // device, slot_cap x int2

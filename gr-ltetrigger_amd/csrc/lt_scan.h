@@ -361,55 +361,6 @@ __device__ __forceinline__ WindowResult resolve_window_lanes(const StripPartial 
   return w;
 }
 
-// The same for partials in global memory, one lane per window (the resolver kernel): the twelve strips' leading
-// halves (m1, p1, s, lb) are fetched together -- twelve loads in flight instead of twenty-four round trips, one per
-// step of the two loops above -- and what else a window needs (the peak strip's ub and flags; rarely a neighbour's
-// flags or strip 0's a0) in one more.  Same decisions, same values.
-__device__ __forceinline__ WindowResult resolve_window_global(const StripPartial *__restrict__ parts)
-{
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  static_assert(offsetof(StripPartial, m1) == 0 && offsetof(StripPartial, p1) == 4 && offsetof(StripPartial, s) == 8 &&
-                    offsetof(StripPartial, lb) == 12 && offsetof(StripPartial, ub) == 16,
-                "the leading 16 bytes of a partial are (m1, p1, s, lb)");
-  v4f h[kStrips];
-#pragma unroll
-  for (int s = 0; s < kStrips; ++s) h[s] = *reinterpret_cast<const v4f *>(parts + s);
-  int best = 0;
-  float bm = h[0].x;
-#pragma unroll
-  for (int s = 1; s < kStrips; ++s) { // strips ascend in lag: strict > keeps the first maximum
-    const float v = h[s].x;
-    if (v > bm) {
-      bm = v;
-      best = s;
-    }
-  }
-  const StripPartial pb = parts[best];
-  WindowResult w;
-  w.exact = !(pb.flags & kPartWide);
-  w.peak_value = bm;
-  w.peak_pos = (bm > -FLT_MAX) ? pb.p1 : 0; // srslte_vec_max_fi returns 0 when nothing beats -FLT_MAX
-  const int lb = pb.lb, ub = pb.ub;
-  float out = pb.s;
-#pragma unroll
-  for (int s = 0; s < kStrips; ++s) {
-    if (s == best) continue;
-    const int p = __float_as_int(h[s].y);
-    const bool inside = p >= lb && p < ub; // that strip's maximum lies on the slope of this lobe
-    if (inside && (parts[s].flags & kPartWide)) w.exact = false;
-    const float v = inside ? h[s].z : h[s].x;
-    if (v > out) out = v;
-  }
-  // empty ranges stand for their first element: the left one is empty exactly when the peak sits at lag <= 2,
-  // the right one when the lobe reaches lag 9726 (avg[9726..9727] = 0)
-  float sl = out;
-  if (w.peak_pos <= 2) sl = parts[0].a0;
-  const float sr = (ub >= kNLags) ? 0.f : out;
-  const float side = sl > sr ? sl : sr;
-  w.psr = w.peak_value / side;
-  return w;
-}
-
 // The deferred form's resolver, one lane per window: heads = the window's 12 StripHeads, rows = its 12 rows (global memory).
 __device__ __forceinline__ bool lag_owned(int s, int lag) { return lag >= kStripPitch * s && lag < kStripPitch * (s + 1) && lag < kNLags; }
 // maximum over strip s's far and the owned lags of its row outside [lb, ub)  (the rare path: a neighbour on the lobe's slope)

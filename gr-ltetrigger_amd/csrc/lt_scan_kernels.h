@@ -478,8 +478,6 @@ struct PlanArgs {
   int call_reach;    // kCallReach (lt_chain_kernel.h)
   // first launch of a run only (first_round): counters to clear behind n_jobs, the one to leave alone, positions to 0
   int n_counters, keep_counter, rebase;
-  int reset_parts;   // ... and lt_batch_reset, applied here instead of in a launch of its own (lt_reset_kernel's rule: bit 0 =
-                     // everything in front of the averages but the CP averages, bit 1 = those; 0 = no reset pending)
   // window cache for the scan rounds (small batches): every job's windows get slots, lt_metric_kernel fills them
   // before the round's scan.  round_slots counts the slots handed out in this round, from 0 in every round (never past
   // slot_cap).
@@ -706,7 +704,6 @@ __global__ __launch_bounds__(256) void lt_plan_kernel(PlanArgs a)
   if (a.first_round) {
     for (int i = threadIdx.x; i < a.n_counters; i += 256)
       if (i != a.keep_counter) a.n_jobs[i] = 0;
-    if (a.reset_parts) reset_chain_states(a.state, a.n_channels * 3, a.reset_parts, threadIdx.x, 256);
     if (a.rebase)
       for (int i = threadIdx.x; i < a.n_channels * 3; i += 256) a.state[i].pos = 0;
     // (one workgroup: what it has just stored is read back -- by other threads, and through atomics that execute in the
