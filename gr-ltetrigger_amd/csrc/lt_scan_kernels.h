@@ -98,6 +98,9 @@ __device__ __forceinline__ int64_t seq_window_pos(const ScanSeq &q, int k)
 constexpr int scan_waves(int G) { return 4 * G; }
 constexpr int scan_threads(int G) { return 64 * scan_waves(G); }
 constexpr int scan_wg_per_job(int G) { return kStrips / G; }
+#ifndef LT_SCAN_EARLY_READY
+#define LT_SCAN_EARLY_READY 1 // a root wave reads its hand-over counters in front of the window's table reads (below)
+#endif
 #ifndef LT_POLL_SLEEP
 #define LT_POLL_SLEEP 1 // s_sleep units (64 clocks) between two looks at a hand-over counter
 #endif
@@ -395,6 +398,19 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
     for (int k = 0; k < n_w; ++k) {
       int ln = lane;
       asm volatile("" : "+v"(ln));
+#if LT_SCAN_EARLY_READY
+      // The hand-over counters first, the stage's twiddles behind them: a wave's LDS reads return in order, so counters read
+      // behind the eight 16-byte table reads would wait for those, and a first look at `ready` taken only after the priorities
+      // are set is a second trip through the LDS -- on every window of every root wave.  Read up front, all three words are back
+      // while the tables are still on their way, and in the usual case (the forward wave is ahead) no poll follows.
+      int rdy0 = __hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int p1v = 0, p2v = 0;
+      if constexpr (kScanGroups == 3) {
+        p1v = __hip_atomic_load(&sync_taken[(g + 1) % 3][root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        p2v = __hip_atomic_load(&sync_taken[(g + 2) % 3][root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       fft::Twiddles tw; // (table reads in flight while the wave waits for the block)
       fft::stageA_twiddles(ln, TW1, tw);
       __builtin_amdgcn_sched_barrier(0);
@@ -403,8 +419,12 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
       if constexpr (kScanGroups == 3) {
         // ... and the workgroup's three strips should finish together: a root wave measures itself against its root's
         // waves of the other two strips (windows taken so far) -- behind them it moves up, ahead of both it steps back
+#if LT_SCAN_EARLY_READY
+        const int p1 = uniform_i32(p1v), p2 = uniform_i32(p2v);
+#else
         const int p1 = uniform_i32(__hip_atomic_load(&sync_taken[(g + 1) % 3][root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const int p2 = uniform_i32(__hip_atomic_load(&sync_taken[(g + 2) % 3][root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+#endif
         const int behind = (k < p1) + (k < p2), ahead = (k > p1) + (k > p2);
         set_wave_priority(1 + behind - (ahead == 2 ? 1 : 0));
       }
@@ -415,6 +435,9 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
           set_wave_priority(((on1 && k < p1) || (on2 && k < p2)) ? 2 : 1);
         }
       }
+#if LT_SCAN_EARLY_READY
+      if (uniform_i32(rdy0) <= k)
+#endif
       while (__hip_atomic_load(&sync_ready[g][my_seq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(LT_POLL_SLEEP);
       LT_LDS_ORDER;
       LT_PSTAMP(0) // waiting for the forward wave
