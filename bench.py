@@ -725,9 +725,9 @@ def config2(torch, lt, dev, device):
             "value": round(n_in / ms / 1e3, 1), "unit": "Msamp/s at the input rate",
             "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": round(algo / (ms * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "note": "one channel: the path's 200 windows are a sequential chain (12 one-strip workgroups whose "
-                                 "root waves take the lag metrics from the window cache, 0.87 us per window, with plan, "
-                                 "lag-metric, resolver and per-record launches around them); "
+                         "note": "one channel: 15 small launches in a row (plan, then lag metrics / cached scan / resolver per "
+                                 "round, per-chain and per-record kernels); a round's windows are dealt to eight waves per "
+                                 "(strip, root) that take the lag metrics from the window cache (lt_scan_cached_kernel); "
                                  "the decimator is VALU-bound (33 taps per input sample, tap-ordered unfused sums)"},
             "cells": sorted(int(c) for c in cells), "ok": cells == {125}}
 

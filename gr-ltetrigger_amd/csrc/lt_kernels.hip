@@ -713,10 +713,21 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     mm.hist_len = R.hist_len; mm.slot_owner = p.slot_owner; mm.slot_pos = p.slot_pos; mm.launch_slots = R.n_jobs + kCtrLaunchSlots;
     mm.slot_cap = R.slot_cap; mm.quota = 0; mm.cache = reinterpret_cast<float *>(R.cache); mm.tab = R.tab;
     const int metric_grid = 4 * (R.n_cus > 0 ? R.n_cus : 256);
+    // cached jobs go through lt_scan_cached_kernel (a round's windows in segments); a job that got no slots -- possible only
+    // when the cache holds fewer than a round's windows for every chain -- stays with lt_scan_kernel, which skips the cached ones
+    CachedScanArgs cs;
+    cs.jobs = nullptr; cs.n_jobs = nullptr; cs.jobs_cap = n_chains; cs.state = state; cs.heads = parts; cs.rows = part_rows;
+    cs.cache = reinterpret_cast<const float *>(R.cache);
+    cs.n_seg = R.cached_segments; cs.light = R.cached_light;
+    if (cs.n_seg > kCachedSegMax) cs.n_seg = kCachedSegMax;
+    if (!(cs.light > 0.01f && cs.light < 0.99f)) cs.light = 0.15f;
+    s.skip_cached = cached_scan && cs.n_seg > 0 ? 1 : 0;
+    const bool all_cached = (int64_t)R.slot_cap >= (int64_t)n_chains * kScanMaxRound;
+    const int cached_grid = ((R.n_channels * kStrips * 3 + 7) / 8) * 8 * (cs.n_seg > 0 ? cs.n_seg : 1);
     LT_LAUNCH(lt_plan_kernel, dim3(1), dim3(256), 0, stream, p);
     for (int r = 0; r < rounds && p.enable; ++r) {
-      s.jobs = q.jobs = jobs2[r & 1];
-      s.n_jobs = R.n_jobs + 2 * r;
+      s.jobs = q.jobs = cs.jobs = jobs2[r & 1];
+      s.n_jobs = cs.n_jobs = R.n_jobs + 2 * r;
       q.plan_next = r + 1 < rounds;
       q.ask = (!q.plan_next && ask_early) ? 1 : 0;
       q.next = p;
@@ -730,7 +741,9 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
         mm.launch_slots = R.n_jobs + kCtrLaunchSlots + r;
         LT_LAUNCH(lt_metric_kernel, dim3((unsigned)metric_grid), dim3(64 * kMetricWaves), 0, stream, mm);
       }
-      if (G == 1) LT_LAUNCH(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
+      if (cached_scan && cs.n_seg > 0) LT_LAUNCH(lt_scan_cached_kernel, dim3((unsigned)cached_grid), dim3(64), 0, stream, cs);
+      if (cached_scan && cs.n_seg > 0 && all_cached) { // (every job of a round has its slots: nothing is left for the transforms)
+      } else if (G == 1) LT_LAUNCH(lt_scan_kernel<1>, dim3(grid), dim3(scan_threads(1)), 0, stream, s);
       else if (G == 2) LT_LAUNCH(lt_scan_kernel<2>, dim3(grid), dim3(scan_threads(2)), 0, stream, s);
       else LT_LAUNCH(lt_scan_kernel<3>, dim3(grid), dim3(scan_threads(3)), 0, stream, s);
       LT_LAUNCH(lt_resolve_kernel, dim3(R.n_channels), dim3(192), 0, stream, q);

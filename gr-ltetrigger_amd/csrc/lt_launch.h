@@ -42,6 +42,8 @@ struct RunLaunch {
   int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
   int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
   int scan_groups = 0;        // strips per scan workgroup: 1, 2 or 3; 0 = chosen from n_channels and n_cus
+  int cached_segments = 8;    // cached jobs (batches of <= 4 channels): waves a round's windows of one (strip, root) are dealt to; 0 = one wave in lt_scan_kernel
+  float cached_light = 0.25f; // ... and what a window that only updates the average costs such a wave, in windows with a search
   int n_cus = 0;              // compute units of the device (0: 256)
   int extra_rounds = 0;       // rounds beyond what an idle chain needs (what the rounds leave over goes through the window cache)
   void *cp_scratch = nullptr; // device, [n_channels*3][rec_cap] x per_record_scratch_bytes(): CP metrics, then the two work lists

@@ -129,6 +129,7 @@ struct ScanArgs {
   const DeviceTables *tab;
   unsigned long long *prof; // diagnostics build only (LT_SCAN_PROF): shader-clock sums per phase of one root wave
   const float *cache;       // window cache (slots of kStrips x 64 * kStripRegs floats), or null
+  int skip_cached = 0;      // cached jobs are lt_scan_cached_kernel's
 };
 
 __device__ __forceinline__ void set_wave_priority(int p)
@@ -173,6 +174,7 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
   const int n_seq = uniform_i32(jp->n_seq), channel = uniform_i32(jp->channel);
   if (n_seq <= 0) return;
   const bool cached = a.cache != nullptr && uniform_i32(jp->cached) != 0;
+  if (cached && a.skip_cached) return;
   // group g = w % 3 owns strip 3 quarter + g; role w / 3: 0 = forward, 1..3 = root 0..2 (the three forward
   // waves land on three different SIMDs)
   const int g = w % kScanGroups, role = w / kScanGroups;
@@ -481,6 +483,131 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
 #endif
     strip_ema_store(st->avg[(sel + 2) % 3], strip, lane, ema);
   }
+}
+
+// ---------------------------------------------------------------- cached jobs: a round's windows in segments
+// A cached job (a batch of <= 4 channels: lt_metric_kernel has formed every window's lag metrics) leaves a root wave of
+// lt_scan_kernel nothing but the average and the strip's head per window -- 330 dependent instructions, 0.8 us, one
+// wave per (strip, root), 36 waves on the whole chip for a channel, window after window: config 2's round of 99 windows
+// was 79 us of that.  A window's average is a recurrence over the windows before it, but a cheap one (14 loads and 7
+// packed operations per lane against the 300 instructions of the head), so the round is cut into kSeg segments and
+// wave j of a (strip, root) runs the average alone -- the same operations in the same order: the same bits -- through
+// the windows in front of its segment and the whole work on its own.  Segments grow shorter towards the end so that all
+// waves finish together: with `light` = a light window's cost over a full one's, b_j = n (1 - q^j) / (1 - q^S),
+// q = 1 - light (measured on config 2, 99-window rounds, us per round: one wave 79; 4 / 8 / 16 / 32 segments 38 / 33 / 33 / 40,
+// light = 0.08 ... 0.25 within 2 us of each other -- a wave has at most 64 loads in flight, four windows' worth, so a light
+// window costs what a quarter of a trip to the L2 costs: profiles/r05_config2_segments.txt).  One-wave workgroups (nothing is shared but the cache lines, and a wave alone on its SIMD issues
+// fastest); the S waves of a (strip, root) on one XCD, whose L2 then serves S - 1 of their S reads of a window.
+struct CachedScanArgs {
+  const ScanJob *jobs;
+  const int *n_jobs;
+  int jobs_cap;
+  ChainState *state;
+  StripHead *heads;
+  float *rows;
+  const float *cache;
+  int n_seg;   // waves per (job, strip, root)
+  float light; // cost of a window that only updates the average, in full windows
+};
+constexpr int kCachedAhead = 8; // windows whose loads are in flight
+constexpr int kCachedSegMax = 32;
+
+__global__ __launch_bounds__(64) void lt_scan_cached_kernel(CachedScanArgs a)
+{
+  constexpr int P = kCachedAhead;
+  const int lane = threadIdx.x;
+  // workgroup -> (unit = (job, strip, root), segment): a unit's segments on one XCD (workgroups go to the XCDs in turn)
+  const int b = blockIdx.x, S = a.n_seg;
+  const int unit = ((b >> 3) / S) * 8 + (b & 7), seg = (b >> 3) % S;
+  const int n_front = a.n_jobs[0], n_back = a.n_jobs[1];
+  int job_i = unit / (kStrips * 3);
+  const int strip = (unit % (kStrips * 3)) / 3, root = unit % 3;
+  if (job_i >= n_front + n_back) return;
+  if (job_i >= n_front) job_i = a.jobs_cap - 1 - (job_i - n_front);
+  const ScanJob *jp = a.jobs + job_i;
+  if (uniform_i32(jp->n_seq) <= 0 || uniform_i32(jp->cached) == 0) return;
+  const int my_seq = uniform_i32(jp->seq_of_root[root]);
+  if (my_seq < 0) return;
+  const ScanSeq sq = uniform_seq(jp->seq[my_seq]);
+  const int n_w = seq_windows(sq);
+  const int chain = uniform_i32(jp->channel) * 3 + root;
+  ChainState *st = a.state + chain;
+  const int sel = st->ema_sel;
+  // this wave's segment [seg_start, seg_end)
+  int seg_start, seg_end;
+  {
+    const float q = 1.f - a.light;
+    float pw = 1.f, q0 = 1.f, q1 = 1.f;
+    for (int i = 0; i < S; ++i) {
+      if (i == seg) q0 = pw;
+      pw *= q;
+      if (i == seg) q1 = pw;
+    }
+    const float scale = (float)n_w / (1.f - pw);
+    seg_start = seg == 0 ? 0 : (int)(scale * (1.f - q0) + 0.5f);
+    seg_end = seg == S - 1 ? n_w : (int)(scale * (1.f - q1) + 0.5f);
+    seg_start = uniform_i32(seg_start < n_w ? seg_start : n_w);
+    seg_end = uniform_i32(seg_end < n_w ? seg_end : n_w);
+  }
+  if (seg_end <= seg_start && !(n_w == 0 && seg == 0)) return;
+  // the average restarts where tracking starts (srslte_pss_reset): nothing in front of that window matters behind it
+  const int k_reset = sq.n_c > 0 ? sq.n_a + sq.n_b : -1;
+  const int k0 = (k_reset >= 0 && seg_start >= k_reset) ? k_reset : 0;
+  ema_t ema;
+  if (sq.zero || k0 > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ema[r] = r < kStripRegs ? 0.f : -FLT_MAX;
+  } else {
+    strip_ema_load(st->avg[sel], strip, lane, ema);
+  }
+  StripHead *heads = a.heads + (int64_t)chain * kScanMaxRound * kStrips + strip;
+  float *rows = a.rows + ((int64_t)chain * kScanMaxRound * kStrips + strip) * kRowLags;
+  const float *m = a.cache + (size_t)uniform_i32(jp->slot_base[root]) * (kStrips * 64 * kStripRegs) + (size_t)strip * (64 * kStripRegs) + lane;
+  float buf[P][kStripRegs];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    if (k0 + p < seg_end) {
+      const float *mn = m + (size_t)(k0 + p) * (kStrips * 64 * kStripRegs);
+#pragma unroll
+      for (int r = 0; r < kStripRegs; ++r) buf[p][r] = mn[64 * r];
+    }
+  for (int k = k0; k < seg_end; k += P) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int kk = k + p;
+      if (kk < seg_end) {
+        float met[kStripRegs];
+#pragma unroll
+        for (int r = 0; r < kStripRegs; ++r) met[r] = buf[p][r];
+        if (kk + P < seg_end) {
+          const float *mn = m + (size_t)(kk + P) * (kStrips * 64 * kStripRegs);
+#pragma unroll
+          for (int r = 0; r < kStripRegs; ++r) buf[p][r] = mn[64 * r];
+        }
+        if (kk == k_reset) {
+          asm volatile("; the average cleared" ::: "memory");
+#pragma unroll
+          for (int r = 0; r < kStripRegs; ++r) ema[r] = 0.f;
+        }
+        strip_ema_apply(strip, ln, met, ema);
+        if (kk >= seg_start) {
+          if (kk < sq.n_a) {
+            if (kk == sq.n_a - 1) strip_ema_store(st->avg[(sel + 1) % 3], strip, ln, ema);
+          } else {
+            StripHead hd;
+            float row;
+            int idx;
+            strip_head_row(ema, strip, ln, hd, row, idx);
+            if (idx >= 0) rows[(int64_t)(kk - sq.n_a) * (kStrips * kRowLags) + idx] = row;
+            if (lane == 0) heads[(int64_t)(kk - sq.n_a) * kStrips] = hd;
+          }
+        }
+      }
+    }
+  }
+  if (seg_end == n_w) strip_ema_store(st->avg[(sel + 2) % 3], strip, lane, ema);
 }
 
 // ---------------------------------------------------------------- plan: the jobs of the next round
