@@ -242,11 +242,24 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
       }                                                                                                  \
     }                                                                                                    \
   }
-  // one chunk: while unit g computes, unit g + 1 (or the next chunk's first) is on its way
+  // one chunk: while unit g computes, unit g + 1 (or the next chunk's first) is on its way.  Scalar loads return in any order,
+  // so a wait for a unit's taps is a wait for everything the counter they share with the LDS reads still holds: taken BEFORE the
+  // next unit's loads are issued it waits for loads that have had a whole unit's FMAs to land; left to the compiler it comes in
+  // front of the unit's first FMA, behind the next unit's loads, and drains those too -- a full trip to the LDS and the scalar
+  // cache in the open, every other unit.
+#ifndef LT_DECIM_EARLY_WAIT
+#define LT_DECIM_EARLY_WAIT 1
+#endif
+#if LT_DECIM_EARLY_WAIT
+#define LT_DECIM_WAIT { __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ __builtin_amdgcn_sched_barrier(0); }
+#else
+#define LT_DECIM_WAIT
+#endif
 #define LT_DECIM_CHUNK(m, kPeel, kMore)                                                                  \
   {                                                                                                      \
     _Pragma("unroll") for (int g = 0; g < G; ++g)                                                        \
     {                                                                                                    \
+      LT_DECIM_WAIT                                                                                      \
       if (g + 1 < G) LT_DECIM_LOAD(m, g + 1, kPeel)                                                      \
       else if (kMore) LT_DECIM_LOAD((m) + 1, 0, ((m) + 1 == m_last))                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                 \
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(kDecimThreads) void lt_decim_kernel(const v2f *__re
   for (int m = 1; m < m_last; ++m) LT_DECIM_CHUNK(m, false, true)
   LT_DECIM_CHUNK(m_last, true, false)
 #undef LT_DECIM_CHUNK
+#undef LT_DECIM_WAIT
 #undef LT_DECIM_FMA
 #undef LT_DECIM_LOAD
 #undef LT_DECIM_X

@@ -31,4 +31,5 @@ with torch.cuda.stream(s):
         times.append(e0.elapsed_time(e1))
 ms = min(times)
 print(f"decimation {rate}, {n_ch} channel(s) x {n_in} samples: {ms * 1e3:.1f} us per launch "
-      f"({n_ch * n_in * 8 / ms / 1e6:.0f} GB/s of input, {n_ch * n_in / ms / 1e6:.1f} Gsamp/s)")
+      f"({n_ch * n_in * 8 / ms / 1e6:.0f} GB/s of input, {n_ch * n_in * (8 + 8 / rate) / ms / 1e6:.0f} GB/s read + written "
+      f"[the algorithmic bytes, 8 + 8/D per input sample], {n_ch * n_in / ms / 1e6:.1f} Gsamp/s)")
