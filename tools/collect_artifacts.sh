@@ -30,6 +30,9 @@ cp "$OUT"/prof_path/*/*kernel_stats.csv "$OUT/${TAG}_kernel_stats_path.csv"
 bash tools/pmc_scan.sh gr-ltetrigger_amd/build/scan_bench lt_scan_kernel 64 64 7 1 > "$OUT/${TAG}_pmc_scan_kernel.txt" 2>&1
 bash tools/pmc_scan.sh python3 lt_decim tools/decim_probe.py 16 50 > "$OUT/${TAG}_pmc_decim_kernel.txt" 2>&1
 for a in "4 16" "8 64" "16 50" "16 1" "8 1"; do python tools/decim_probe.py $a; done > "$OUT/${TAG}_decim_probe.txt" 2>&1
+# BASELINE configs[1] (one 15.36 Msps channel): the kernels of one pass
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_config2" -- python3 tools/config2_timeline.py > "$OUT/config2.out" 2> "$OUT/config2.err"
+{ cat "$OUT/config2.out"; python tools/timeline.py "$OUT/prof_config2"; python tools/config2_timeline.py; } > "$OUT/${TAG}_timeline_config2.txt"
 # marginal cells: a step's kernels at -4 and 0 dB
 for level in 3 4; do for snr in -4 0; do
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_snr${snr}_l$level" -- python3 bench.py --snr-db $snr --window-cache $level --steps 6 --warmup 3 --no-end-to-end --no-config2 --no-config5 --no-cpu-baseline --no-overlap-leg --no-steady-leg --no-streaming --no-oracle-check > "$OUT/bench_snr${snr}_l$level.json" 2> /dev/null
