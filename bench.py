@@ -722,6 +722,7 @@ def config2(torch, lt, dev, device):
     algo = 8.0 * n_in
     return {"workload": "1 channel, lte_frame_50prb_cellid_125 looped x100 @15.36 Msps (BASELINE configs[1]), decimation 8",
             "device_ms": round(ms, 4), "decimator_ms": round(dms, 4), "path_ms": round(ms - dms, 4),
+            "launches": 1 + int(b.last_launch_count()),  # the decimator's + lt_batch_run's
             "value": round(n_in / ms / 1e3, 1), "unit": "Msamp/s at the input rate",
             "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": round(algo / (ms * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
