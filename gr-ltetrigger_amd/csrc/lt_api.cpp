@@ -563,7 +563,9 @@ void alloc_window_cache(lt_batch *b)
   const int64_t windows = b->max_samples / LT_HALF_FRAME_LEN + 2;
   int64_t quota = std::min<int64_t>(windows, lt::cache_max_per_chain());
   quota = std::min<int64_t>(quota, kCacheBudget / lt::cache_slot_bytes() / nchains);
-  const int64_t per_chain = b->n_channels <= 4 ? std::max<int64_t>(3 * windows + 16, quota) : quota;
+  // (batches that scan from the cache: a round's windows of every chain have slots at once -- at most scan_max_round() per chain;
+  // the per-chain part's requests come after the rounds and use the same slots again)
+  const int64_t per_chain = b->n_channels <= lt::cached_scan_max_channels() ? std::max<int64_t>(lt::scan_max_round(), quota) : quota;
   if (quota < 1 || nchains * per_chain > 0x7fffffff / 16) return;
   b->cache_slots = (int)(nchains * per_chain);
   b->cache_quota = (int)quota;

@@ -596,7 +596,13 @@ __global__ __launch_bounds__(64) void lt_delay_kernel(long long ticks)
 namespace lt {
 
 constexpr int kMaxRounds = 256; // scan rounds per run at most (the per-chain kernel takes what is left)
-constexpr int kCachedScanMaxChannels = 4; // batches up to this size scan from the window cache (lt_batch_set_window_cache 2)
+// Batches up to this size scan from the window cache (lt_batch_set_window_cache >= 2): lt_metric_kernel forms a round's lag
+// metrics chip-wide, lt_scan_cached_kernel runs the averages and heads in segments.  Through the transforms a round is a serial
+// chain of windows per strip whatever the batch (2.3 us per window with one strip per workgroup); from the cache it costs 1.5 x
+// the transforms (every root its own forward one) but all of them at once.  One lt_batch_run of N channels x 1 s, us (one box,
+// tools/cached_crossover.py), transforms / cache: N = 5: 518 / 298, 8: 527 / 361, 12: 536 / 466, 16: 546 / 570, 24: 689 / 788.
+constexpr int kCachedScanMaxChannels = 12;
+int cached_scan_max_channels() { return kCachedScanMaxChannels; }
 
 int call_reach() { return kCallReach; }
 int scan_job_bytes() { return (int)sizeof(ScanJob); }
@@ -714,7 +720,7 @@ hipError_t launch_run(const RunLaunch &R, hipStream_t stream, hipStream_t record
     // and a round is bound by a root wave's instruction stream -- without the transforms that stream is 330
     // instructions instead of 840
     const bool cached_scan = p.enable && R.cache && R.slot_owner && R.slot_pos && R.slot_cap > 0 && R.cache_level >= 2 &&
-                             R.n_channels <= kCachedScanMaxChannels;
+                             R.n_channels <= cached_scan_max_channels();
     p.cached = cached_scan ? 1 : 0;
     p.slot_owner = reinterpret_cast<int2 *>(R.slot_owner);
     p.slot_pos = reinterpret_cast<int64_t *>(R.slot_pos);

@@ -42,7 +42,7 @@ struct RunLaunch {
   int seg_first = 2;          // windows per job in the first scan round (cells present from the start fire right away)
   int seg_len = 0;            // windows per job in the later rounds (<= scan_max_round()); 0 = the chunk's windows split evenly over as few rounds as possible
   int scan_groups = 0;        // strips per scan workgroup: 1, 2 or 3; 0 = chosen from n_channels and n_cus
-  int cached_segments = 8;    // cached jobs (batches of <= 4 channels): waves a round's windows of one (strip, root) are dealt to; 0 = one wave in lt_scan_kernel
+  int cached_segments = 8;    // cached jobs (batches of <= cached_scan_max_channels()): waves a round's windows of one (strip, root) are dealt to; 0 = one wave in lt_scan_kernel
   float cached_light = 0.25f; // ... and what a window that only updates the average costs such a wave, in windows with a search
   int n_cus = 0;              // compute units of the device (0: 256)
   int extra_rounds = 0;       // rounds beyond what an idle chain needs (what the rounds leave over goes through the window cache)
@@ -80,6 +80,7 @@ int call_reach();
 int scan_job_bytes();
 int scan_parts_bytes_per_chain();
 int scan_max_round();
+int cached_scan_max_channels(); // batches up to this size scan from the window cache (levels >= 2)
 int scan_max_rounds();
 int scan_counter_ints();
 int per_record_scratch_bytes();

@@ -486,7 +486,7 @@ template <int kScanGroups> __global__ __launch_bounds__(scan_threads(kScanGroups
 }
 
 // ---------------------------------------------------------------- cached jobs: a round's windows in segments
-// A cached job (a batch of <= 4 channels: lt_metric_kernel has formed every window's lag metrics) leaves a root wave of
+// A cached job (a batch of <= 12 channels: lt_metric_kernel has formed every window's lag metrics) leaves a root wave of
 // lt_scan_kernel nothing but the average and the strip's head per window -- 330 dependent instructions, 0.8 us, one
 // wave per (strip, root), 36 waves on the whole chip for a channel, window after window: config 2's round of 99 windows
 // was 79 us of that.  A window's average is a recurrence over the windows before it, but a cheap one (14 loads and 7

@@ -176,11 +176,11 @@ int lt_batch_reset(lt_batch *b);
  * lt_batch_create; a mode never changes behind the caller's back. */
 int lt_batch_set_mode(lt_batch *b, int mode);
 int lt_batch_get_mode(lt_batch *b);
-/* Window cache, levels 0 to 4 (default 3).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
+/* Window cache, levels 0 to 4 (default 4).  Level 1: what the scan rounds leave over -- chains that keep firing and losing a weak
  * cell, every chain in mode 0 -- the per-chain kernel takes in two passes: the first lists the windows every such chain
  * has ahead of it on its present timing, lt_metric_kernel forms their lag metrics for all chains at once, chip-wide,
  * and the second pass runs general_work on them (a window off the list goes through the transforms there and then).
- * Level 2: in batches of up to four channels -- whose scan rounds are bound by the instruction stream of one root
+ * Level 2: in batches of up to twelve channels -- whose scan rounds are bound by the instruction stream of one root
  * wave per CU, not by the chip -- the rounds' windows are listed too and the scan takes their lag metrics from the cache
  * (no transforms in the round itself).  Level 3 = level 2, with the per-chain kernel's two passes (and lt_metric_kernel
  * between them) launched only while chains ask for the cache: the kernel tells the host, through two words of pinned memory,
@@ -205,9 +205,9 @@ int lt_batch_get_mode(lt_batch *b);
  * this level; levels 0 to 3 are bit-identical across those too.  THE DEFAULT (since round 5).
  * Footprint: every chain owns min(windows of max_samples, 256) slots of 43 008 bytes (1.7 GB for 64 channels x 1 s; at most
  * 48 GB: beyond that the per-chain share shrinks and what lies behind a chain's slots goes through the transforms);
- * batches of up to four channels three times the windows.  Allocated by lt_batch_create, freed by level 0 and allocated
+ * batches of up to twelve channels at least 128 slots per chain (a scan round's windows).  Allocated by lt_batch_create, freed by level 0 and allocated
  * again by 1 ... 4 (if the memory cannot be had the batch runs as at level 0).  The slots of a scan round (levels >= 2, up to
- * four channels) are free again after the round: a capture of any length scans from the cache. */
+ * twelve channels) are free again after the round: a capture of any length scans from the cache. */
 int lt_batch_set_window_cache(lt_batch *b, int level);
 /* Diagnostics of the last run: stats[0] = windows asked for, [1] = searches of the second pass served from the cache,
  * [2] = searches of the second pass that went through the transforms, [3] = chains that waited for the cache,

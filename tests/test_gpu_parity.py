@@ -611,7 +611,7 @@ def test_window_cache_gives_the_same_records(lt, oracle, frames_192, mode):
         seen.append(b.cache_stats())
     assert seen[0][1] == 0 and seen[0][3] == 0, f"a fresh batch's first run has one pass: {seen[0]}"
     assert seen[1][3] > 0 and seen[1][1] > 50 and seen[2][1] > 50, f"two passes once chains have asked: {seen[1:]}"
-    # a small batch (up to four channels) at level 2: the scan rounds themselves take their lag metrics
+    # a small batch (up to twelve channels) at level 2: the scan rounds themselves take their lag metrics
     # from the cache -- the first three channels' records are those they have in the batch of six
     if mode == 1:
         for level in (2, 1):

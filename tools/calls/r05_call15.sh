@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 15: the tree as committed -- suite, smoke, the driver's command
+# round 5, call 15: the tree as it stands -- suite, smoke, the driver's command
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -52,4 +52,7 @@ timeout -k 10 500 python tools/stress_parity.py --scenes 300 --seed0 9000 --wind
 cp "$OUT/stress_l3/stress_parity.json" "$OUT/${TAG}_stress_parity_level3.json"
 timeout -k 10 500 python tools/stress_parity.py --scenes 200 --seed0 12000 --variants 3 --out "$OUT/stress_var" > "$OUT/stress_var.json" 2> "$OUT/stress_var.err"
 cp "$OUT/stress_var/stress_parity.json" "$OUT/${TAG}_stress_parity_variants.json"
+# (scenes of 3 .. 11 channels scan from the window cache since the limit is 12: batches of ~ 50 channels for the rounds through the transforms)
+timeout -k 10 500 python tools/stress_parity.py --scenes 30 --seed0 15000 --stack 7 --out "$OUT/stress_stack" > "$OUT/stress_stack.json" 2> "$OUT/stress_stack.err"
+cp "$OUT/stress_stack/stress_parity.json" "$OUT/${TAG}_stress_parity_stack7.json"
 echo ALLDONE
