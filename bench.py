@@ -670,7 +670,15 @@ def streaming(torch, lt, iq, n_ch, n, device, chunk_samples, ref_recs, seconds=N
                         got[c].append(r.copy())
         return time.perf_counter() - t_start, per_chunk, got
     _, _, got = one_pass(False)  # warm-up, and the records that are compared
-    dt, per_chunk, _ = one_pass(True)
+    # (the warm-up pass leaves tens of thousands of small arrays alive: a collection of the oldest generation in the middle of
+    # the timed pass was one chunk of 40 ms among a hundred of 0.2 -- the interpreter's pause, not the path's)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        dt, per_chunk, _ = one_pass(True)
+    finally:
+        gc.enable()
     launches = b.last_launch_count()
     b.close()
     # the records of the stream = those of the single run up to where the stream ends (same parity bar as every comparison;
